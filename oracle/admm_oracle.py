@@ -1,0 +1,494 @@
+"""CPU oracle for the mixed-graph ADMM hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy/SciPy *restatement* of the algorithm in the reference
+(JiQi-da/Mixed-Graph-ADMM, ``ADMM.py`` / ``utils.py`` / ``CG_script.py``).  It is
+written in sparse-matrix form (explicit CSR matrices for W_u, W_d and the exact
+transpose W_d^T) rather than the reference's gather / scatter_add tables, so that it is an
+independent check of both the reference semantics and the HIP kernels.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  The product package (``mixed-graph-admm_amd/mgadmm``) never does and
+fails loudly when its HIP extension is missing.
+
+Parity status: PINNED.  ``tests/test_oracle_golden.py`` checks every function here against
+golden vectors produced by importing and running the reference itself in the authoring
+container (``tests/golden/gen_golden.py``), and against the literal known-answer values the
+reference holds (``CG_script.py:47-56``, ``utils.py:297-300``, ``directed_graph.ipynb``).
+
+Reference citations (file:line into /root/reference) are given per function.
+"""
+from __future__ import annotations
+
+import heapq
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import scipy.sparse as sp
+
+ABLATIONS = ("None", "DGTV", "DGLR", "UT")
+
+
+# --------------------------------------------------------------------------------------
+# Graph tables (reference: utils.py:156-258)
+# --------------------------------------------------------------------------------------
+def connect_list(n_nodes, edges, dists):
+    """Padded physical adjacency.  Follows utils.py:156-181.
+
+    Column 0 is the node itself (distance 0); neighbours are filled from the highest slot
+    downwards in edge order (the reference decrements a per-node counter), unused slots hold
+    -1 / +inf.  Returns (int64 (N,kmax+1), float32 (N,kmax+1)).
+    """
+    edges = np.asarray(edges).astype(np.int64)
+    dists = np.asarray(dists)
+    counts = np.zeros(n_nodes, dtype=np.int64)
+    for e in edges:
+        counts[e[0]] += 1
+    k = int(counts.max())
+    cl = -np.ones((n_nodes, k + 1), dtype=np.int64)
+    dl = np.full((n_nodes, k + 1), np.inf, dtype=np.float32)
+    for i in range(len(edges)):
+        s = edges[i, 0]
+        cl[s, counts[s]] = edges[i, 1]
+        dl[s, counts[s]] = dists[i]
+        counts[s] -= 1
+    cl[:, 0] = np.arange(n_nodes)
+    dl[:, 0] = 0.0
+    return cl, dl
+
+
+def k_nearest_neighbors(n_nodes, edges, dists, k):
+    """k nearest nodes by shortest-path distance.  Follows utils.py:183-204.
+
+    The reference runs networkx ``single_source_dijkstra_path_length`` from every node and takes
+    ``heapq.nsmallest(k+1)`` (a stable selection over the dict in settle order).  Restated here as
+    a Dijkstra truncated after k+1 settled nodes with networkx's (distance, push-counter) heap
+    ordering, which yields the same nodes in the same order.  Returns (int64 (N,k+1), float32).
+    """
+    edges = np.asarray(edges).astype(np.int64)
+    dists = np.asarray(dists, dtype=np.float64)
+    adj = [dict() for _ in range(n_nodes)]  # insertion-ordered, later duplicates overwrite
+    for i in range(len(edges)):
+        adj[int(edges[i, 0])][int(edges[i, 1])] = float(dists[i])
+    nn = -np.ones((n_nodes, k + 1), dtype=np.int64)
+    nd = np.full((n_nodes, k + 1), np.inf, dtype=np.float32)
+    for src in range(n_nodes):
+        settled = {}
+        seen = {src: 0.0}
+        cnt = 0
+        heap = [(0.0, cnt, src)]
+        while heap and len(settled) < k + 1:
+            d, _, v = heapq.heappop(heap)
+            if v in settled:
+                continue
+            settled[v] = d
+            for u, w in adj[v].items():
+                vu = d + w
+                if u in settled:
+                    continue
+                if u not in seen or vu < seen[u]:
+                    seen[u] = vu
+                    cnt += 1
+                    heapq.heappush(heap, (vu, cnt, u))
+        items = sorted(settled.items(), key=lambda kv: kv[1])  # stable == heapq.nsmallest
+        for j, (node, dist) in enumerate(items[: k + 1]):
+            nn[src, j] = node
+            nd[src, j] = dist
+    return nn, nd
+
+
+def _default_sigma(cl, dl):
+    m = (cl != -1) & (dl != 0)
+    v = dl[m]
+    return max(float(v.max()) / 50, float(v.min()) * 50)
+
+
+def undirected_weights(cl, dl, u_sigma=None):
+    """u_ew (N,k) float32.  Follows utils.py:206-238 (regularized=True).
+
+    w = exp(-d/sigma) on columns 1..k, 0 at pads; w_ij /= sqrt(deg_i * deg_{cl[i,j]}) where a
+    pad index -1 wraps to the last node (quirk Q5, harmless: the weight there is 0).
+    All arithmetic in float32 like the reference's torch.float tables.
+    """
+    cl = np.asarray(cl)
+    dl = np.asarray(dl, dtype=np.float32)
+    if u_sigma is None:
+        u_sigma = _default_sigma(cl, dl)
+    w = np.exp(-dl[:, 1:] / np.float32(u_sigma)).astype(np.float32)
+    w[cl[:, 1:] == -1] = 0
+    deg = w.sum(1, dtype=np.float32)
+    deg_j = deg[cl[:, 1:]]
+    dij = (deg[:, None] * deg_j).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = np.where(dij > 0, np.float32(1) / np.sqrt(dij, dtype=np.float32), np.float32(0))
+    return (w * inv).astype(np.float32)
+
+
+def directed_weights(cl, dl, d_sigma=None):
+    """d_ew (N,k+1) float32, row-normalised incl. the self column.  Follows utils.py:240-258."""
+    cl = np.asarray(cl)
+    dl = np.asarray(dl, dtype=np.float32)
+    if d_sigma is None:
+        d_sigma = _default_sigma(cl, dl)
+    with np.errstate(over="ignore"):
+        w = np.exp(-dl / np.float32(d_sigma)).astype(np.float32)
+    w[cl == -1] = 0
+    deg = w.sum(1, dtype=np.float32)
+    with np.errstate(divide="ignore"):
+        inv = np.where(deg > 0, np.float32(1) / deg, np.float32(0)).astype(np.float32)
+    return (w * inv[:, None]).astype(np.float32)
+
+
+def skip_tables(T, skip):
+    """Temporal skip-connection weights wt (T,skip) float32 (identical for every node) and
+    time_list (T,skip).  Follows ADMM.py:41-52: ones.tril(-1) over (T,skip), row-normalised with
+    the [0,0] guard, i.e. row t has weight 1/min(t,skip) on s < min(t,skip)."""
+    w = np.tril(np.ones((T, skip), dtype=np.float32), -1)
+    w[0, 0] = 1
+    w = w / w.sum(-1, keepdims=True)
+    w[0, 0] = 0
+    tl = np.arange(T)[:, None] - np.arange(1, skip + 1)[None, :]
+    return w.astype(np.float32), tl
+
+
+def tables_to_csr(cl, u_ew, d_ew, dtype=np.float64):
+    """CSR matrices W_u (cols cl[:,1:]), W_d (cols cl[:,0:]); pads dropped, duplicates summed."""
+    cl = np.asarray(cl)
+    N = cl.shape[0]
+
+    def build(cols, vals):
+        rows = np.repeat(np.arange(N), cols.shape[1])
+        c = cols.reshape(-1)
+        v = np.asarray(vals, dtype=np.float32).astype(dtype).reshape(-1)
+        keep = c != -1
+        return sp.csr_matrix((v[keep], (rows[keep], c[keep])), shape=(N, N))
+
+    Wu = build(cl[:, 1:], u_ew)
+    Wd = build(cl, d_ew) if d_ew is not None else None
+    return Wu, Wd
+
+
+# --------------------------------------------------------------------------------------
+# Initial guesses (reference: ADMM.py:766-811)
+# --------------------------------------------------------------------------------------
+def initial_guess(y, t_in, T):
+    """Per-(b,n,c) least-squares line through the t_in observed steps, extrapolated to T.
+
+    Follows ADMM.py:766-781, including its mixed precision: the time axis and its moments are
+    float32 (0-d float32 scalars combine with float64 data at their float32-rounded values).
+    """
+    t = np.arange(0, t_in, dtype=np.float32)
+    tm = t.mean(dtype=np.float32)
+    t2m = (t ** 2).mean(dtype=np.float32)
+    den = np.float32(t2m - tm ** 2)
+    ym = y.mean(1)
+    w = ((t[None, :, None, None] * y).mean(1) - tm * ym) / den
+    b = ym - w * tm
+    t1 = np.arange(t_in, T, dtype=np.float32)
+    pred = w[:, None] * t1[None, :, None, None] + b[:, None]
+    return np.concatenate((y, pred.astype(y.dtype)), 1)
+
+
+def initial_interpolation(y, mask):
+    """Masked per-(b,n,c) regression; unknown entries filled with the fitted line.
+    Follows ADMM.py:783-811 (t is float32; mask keeps its own dtype, typically float32)."""
+    B, T, N, C = y.shape
+    t = np.broadcast_to(np.arange(T, dtype=np.float32)[None, :, None, None], (B, T, N, C))
+    n_data = mask.sum(1)
+    t_mean = (t * mask).sum(1) / n_data
+    y_mean = (y * mask).sum(1) / n_data
+    ty_mean = (t * y * mask).sum(1) / n_data
+    t2_mean = (t ** 2 * mask).sum(1) / n_data
+    w = (ty_mean - t_mean * y_mean) / (t2_mean - t_mean ** 2)
+    b = y_mean - w * t_mean
+    x = w[:, None] * t + b[:, None]
+    return x * (1 - mask) + y
+
+
+def soft_threshold(s, d):
+    """sign(s) * max(|s| - d, 0)  (ADMM.py:405-408; thresholded entries come out as -0.0/0.0)."""
+    u = np.abs(s) - d
+    return np.sign(s) * u * (u > 0)
+
+
+def conjugate_gradient(A, b, x0=None, tol=1e-10, max_iter=1000):
+    """Dense scalar CG.  Follows CG_script.py:3-44 (same recurrence as CG_solver)."""
+    x = np.zeros_like(b) if x0 is None else x0.copy()
+    r = b - A @ x
+    p = r.copy()
+    rr = r @ r
+    for k in range(max_iter):
+        Ap = A @ p
+        alpha = rr / (p @ Ap)
+        x = x + alpha * p
+        r = r - alpha * Ap
+        rr_new = r @ r
+        beta = rr_new / rr
+        rr = rr_new
+        if np.sqrt(rr) < tol:
+            return x, k + 1
+        p = r + beta * p
+    return x, max_iter
+
+
+# --------------------------------------------------------------------------------------
+# The solver
+# --------------------------------------------------------------------------------------
+@dataclass
+class History:
+    p_res_list: list = field(default_factory=list)
+    d_res_list: list = field(default_factory=list)
+    x_shift_list: list = field(default_factory=list)
+    delta_x_per_step: list = field(default_factory=list)
+    GLR_list: list = field(default_factory=list)
+    DGTV_list: list = field(default_factory=list)
+    DGLR_list: list = field(default_factory=list)
+    recover_list: list = field(default_factory=list)
+    CG_iter_x: list = field(default_factory=list)
+    CG_iter_zu: list = field(default_factory=list)
+    CG_iter_zd: list = field(default_factory=list)
+    alpha_x: list = field(default_factory=list)
+    beta_x: list = field(default_factory=list)
+    alpha_zu: list = field(default_factory=list)
+    beta_zu: list = field(default_factory=list)
+    alpha_zd: list = field(default_factory=list)
+    beta_zd: list = field(default_factory=list)
+
+
+class OracleADMM:
+    """Restatement of ``ADMM_algorithm`` (ADMM.py:11-648) on explicit sparse matrices.
+
+    mode:
+      'knn'      kNN-directed temporal graph (use_kNN=True, use_line_graph=False)
+      'physical' use_kNN=False: the transpose is taken by gathering with the same table (Q4)
+      'line'     use_line_graph=True (skip_connection >= 1)
+    Batched semantics: B independent B=1 reference runs (per-sample CG convergence, Q6);
+    residual norms are Frobenius norms over the whole batch tensor like ADMM.py:612-636.
+    """
+
+    def __init__(self, cl, u_ew, d_ew, ADMM_info, *, mode="knn", ablation="None", t_in=12, T=24,
+                 skip_connection=1, bug_compat=True):
+        assert ablation in ABLATIONS
+        self.cl = np.asarray(cl)
+        self.N = self.cl.shape[0]
+        self.mode, self.ablation, self.t_in, self.T = mode, ablation, t_in, T
+        self.skip = skip_connection
+        self.bug_compat = bug_compat
+        for k in ("rho", "rho_u", "rho_d", "mu_u", "mu_d1", "mu_d2"):
+            setattr(self, k, ADMM_info[k])
+        self.max_CG_iter, self.CG_tol = 100, 1e-8          # ADMM.py:76-80
+        self.ADMM_tol, self.max_ADMM_iter = 1e-6, 150
+        u_ew = np.asarray(u_ew, dtype=np.float32)
+        if u_ew.ndim == 3:   # (T,N,k) time-expanded table: identical slices (utils.py:294-295)
+            u_ew = u_ew[0]
+        if mode == "line":
+            self.Wu, _ = tables_to_csr(self.cl, u_ew, None)
+            self.wt, self.time_list = skip_tables(T, skip_connection)
+            self.Wd = self.WdT = None
+        else:
+            d_ew = np.asarray(d_ew, dtype=np.float32)
+            if d_ew.ndim == 3:
+                d_ew = d_ew[0]
+            self.Wu, self.Wd = tables_to_csr(self.cl, u_ew, d_ew)
+            self.WdT = self.Wd.T.tocsr() if mode == "knn" else self.Wd
+        self.res_name = ["zu"]
+        if ablation in ("None", "DGLR"):
+            self.res_name.append("phi")
+        if ablation != "DGLR":
+            self.res_name.append("zd")
+        self.hist = History()
+        self._wcache = {}
+
+    # ---- spatial matvec on (B,T,N,C) arrays --------------------------------------------
+    def _sp(self, W, x):
+        B, T, N, C = x.shape
+        X2 = np.ascontiguousarray(x.transpose(2, 0, 1, 3)).reshape(N, -1)
+        if W.dtype != x.dtype:           # float32 signal: float32 weights (exact: tables are float32)
+            key = (id(W), x.dtype.str)
+            W = self._wcache.setdefault(key, W.astype(x.dtype))
+        Y2 = W @ X2
+        return Y2.reshape(N, B, T, C).transpose(1, 2, 0, 3)
+
+    def apply_op_Lu(self, x):
+        """(I - W_u) per time slice.  ADMM.py:138-148."""
+        return x - self._sp(self.Wu, x)
+
+    def apply_op_Ldr(self, x):
+        """y[t] = x[t] - W_d x[t-1] (t>=1), y[0] = 0.  ADMM.py:150-177."""
+        y = np.zeros_like(x)
+        if self.mode == "line":
+            T = x.shape[1]
+            for t in range(1, T):
+                acc = np.zeros_like(x[:, t])
+                for s in range(min(t, self.skip)):
+                    acc = acc + self.wt[t, s].astype(x.dtype) * x[:, t - 1 - s]
+                y[:, t] = x[:, t] - acc
+            return y
+        y[:, 1:] = x[:, 1:] - self._sp(self.Wd, x[:, :-1])
+        return y
+
+    def apply_op_Ldr_T(self, x):
+        """Transpose of Ldr; with bug_compat the kNN/physical branch adds the identity on the
+        t=0 block (Q1, ADMM.py:221-222).  ADMM.py:179-223."""
+        T = x.shape[1]
+        y = x.copy()
+        if self.mode == "line":
+            y[:, 0] = 0
+            for t in range(T - 1):
+                acc = np.zeros_like(x[:, t])
+                for s in range(self.skip):
+                    tt = t + 1 + s
+                    if tt < T:
+                        acc = acc + self.wt[tt, s].astype(x.dtype) * x[:, tt]
+                y[:, t] = y[:, t] - acc
+            return y
+        ff = self._sp(self.WdT, x[:, 1:])
+        y[:, :-1] = x[:, :-1] - ff
+        if not self.bug_compat:
+            y[:, 0] = -ff[:, 0]
+        return y
+
+    def apply_op_cLdr(self, x):
+        return self.apply_op_Ldr_T(self.apply_op_Ldr(x))          # ADMM.py:225-228
+
+    # ---- left-hand sides (ADMM.py:371-399) ---------------------------------------------
+    def LHS_x(self, x, mask=None):
+        if mask is None:
+            HtHx = x.copy()
+            HtHx[:, self.t_in:] = 0
+        else:
+            HtHx = x * mask
+        a = self.ablation
+        if a == "None":
+            return HtHx + (self.rho_u + self.rho_d) / 2 * x + self.rho / 2 * self.apply_op_cLdr(x)
+        if a == "DGLR":
+            return HtHx + self.rho / 2 * self.apply_op_cLdr(x) + self.rho_u / 2 * x
+        return HtHx + (self.rho_u + self.rho_d) / 2 * x      # 'DGTV', 'UT'
+
+    def LHS_zu(self, z):
+        return self.mu_u * self.apply_op_Lu(z) + self.rho_u / 2 * z
+
+    def LHS_zd(self, z):
+        return self.mu_d2 * self.apply_op_cLdr(z) + self.rho_d / 2 * z
+
+    def phi_direct(self, x, gamma):
+        return soft_threshold(self.apply_op_Ldr(x) - gamma / self.rho, self.mu_d1 / self.rho)
+
+    # ---- regularisers (ADMM.py:230-246) ------------------------------------------------
+    def GLR(self, x):
+        return (x * self.apply_op_Lu(x)).sum((1, 2, 3)).mean()
+
+    def DGLR(self, x):
+        return (self.apply_op_Ldr(x) ** 2).sum((1, 2, 3)).mean()
+
+    def DGTV(self, x):
+        return np.abs(self.apply_op_Ldr(x)).sum((1, 2, 3)).mean()
+
+    # ---- CG (ADMM.py:329-368), per-sample convergence -----------------------------------
+    def CG_solver(self, LHS, RHS, x0=None, **kw):
+        """Returns (x, iters (B,) int with -1 = not converged, alphas (K,B), betas (K,B)).
+        Rows of alphas/betas past a sample's own iteration count are NaN."""
+        B = RHS.shape[0]
+        x = np.zeros_like(RHS) if x0 is None else x0.copy()
+        r = RHS - LHS(x, **kw)
+        p = r.copy()
+        rr = (r * r).sum((1, 2, 3))
+        active = np.ones(B, dtype=bool)
+        iters = -np.ones(B, dtype=np.int64)
+        alphas, betas = [], []
+        for k in range(self.max_CG_iter):
+            Ap = LHS(p)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                alpha = rr / (p * Ap).sum((1, 2, 3))
+                a = np.where(active, alpha, 0.0).astype(RHS.dtype)
+                x = x + a[:, None, None, None] * p
+                r = r - a[:, None, None, None] * Ap
+                rr_new = (r * r).sum((1, 2, 3))
+                beta = rr_new / rr
+            alphas.append(np.where(active, alpha, np.nan))
+            betas.append(np.where(active, beta, np.nan))
+            rr = np.where(active, rr_new, rr)
+            done = active & (np.sqrt(rr) < self.CG_tol)
+            iters[done] = k + 1
+            active = active & ~done
+            if not active.any():
+                break
+            bb = np.where(active, beta, 0.0).astype(RHS.dtype)
+            p = np.where(active[:, None, None, None], r + bb[:, None, None, None] * p, p)
+        return x, iters, np.array(alphas), np.array(betas)
+
+    # ---- the combined ADMM loop (ADMM.py:511-648) -------------------------------------
+    def combined_loop(self, y, mask=None, n_iters=None):
+        a = self.ablation
+        h = self.hist = History()
+        x = initial_guess(y, self.t_in, self.T) if mask is None else initial_interpolation(y, mask)
+        gamma_u = np.ones_like(x) * 0.1
+        gamma_d = np.ones_like(x) * 0.1
+        has_phi = a in ("None", "DGLR")
+        has_zd = a != "DGLR"
+        if has_phi:
+            gamma = np.ones_like(x) * 0.1
+            phi = self.apply_op_Ldr(x)
+        zu, zd = x.copy(), x.copy()
+        Hty = np.zeros_like(x)
+        Hty[:, : y.shape[1]] = y
+        B = x.shape[0]
+        max_iter = self.max_ADMM_iter if n_iters is None else n_iters
+        for i in range(max_iter):
+            x_old, zu_old, zd_old = x, zu, zd
+            if a in ("DGTV", "UT"):
+                RHS_x = (self.rho_u * zu + self.rho_d * zd) / 2 - (gamma_u + gamma_d) / 2 + Hty
+            elif a == "None":
+                RHS_x = (self.apply_op_Ldr_T(gamma + self.rho * phi) / 2
+                         + (self.rho_u * zu + self.rho_d * zd) / 2 - (gamma_u + gamma_d) / 2 + Hty)
+            else:
+                RHS_x = (self.apply_op_Ldr_T(gamma + self.rho * phi) / 2
+                         + self.rho_u * zu / 2 - gamma_u / 2 + Hty)
+            x, it, al, be = self.CG_solver(self.LHS_x, RHS_x, x_old, mask=mask)
+            h.CG_iter_x.append(it); h.alpha_x.append(al); h.beta_x.append(be)
+            zu, it, al, be = self.CG_solver(self.LHS_zu, gamma_u / 2 + self.rho_u / 2 * x, zu_old)
+            h.CG_iter_zu.append(it); h.alpha_zu.append(al); h.beta_zu.append(be)
+            if has_zd:
+                zd, it, al, be = self.CG_solver(self.LHS_zd, gamma_d / 2 + self.rho_d / 2 * x, zd_old)
+                h.CG_iter_zd.append(it); h.alpha_zd.append(al); h.beta_zd.append(be)
+            gamma_u = gamma_u + self.rho_u * (x - zu)
+            if has_zd:
+                gamma_d = gamma_d + self.rho_d * (x - zd)
+            if has_phi:
+                phi_old = phi
+                phi = self.phi_direct(x, gamma)
+                gamma = gamma + self.rho * (phi - self.apply_op_Ldr(x))
+            pri, dual = [], []
+            h.x_shift_list.append(float(np.linalg.norm(x - x_old)))
+            dx = (x - x_old).mean(0)
+            h.delta_x_per_step.append(np.sqrt((dx ** 2).sum((1, 2))))
+            pri.append(float(np.linalg.norm(x - zu)))
+            dual.append(float(np.linalg.norm(zu - zu_old)))
+            h.GLR_list.append(float(self.GLR(x)))
+            Hx = x * mask if mask is not None else x[:, : self.t_in]
+            h.recover_list.append(float(np.linalg.norm(Hx - y)))
+            if has_phi:
+                pri.append(float(np.linalg.norm(phi - self.apply_op_Ldr(x))))
+                dual.append(float(np.linalg.norm(phi - phi_old)))
+                h.DGTV_list.append(float(self.DGTV(x)))
+            if has_zd:
+                pri.append(float(np.linalg.norm(x - zd)))
+                dual.append(float(np.linalg.norm(zd - zd_old)))
+                h.DGLR_list.append(float(self.DGLR(x)))
+            h.p_res_list.append(pri)
+            h.d_res_list.append(dual)
+            if max(pri) < self.ADMM_tol and max(dual) < self.ADMM_tol:
+                break
+        self.state = dict(x=x, zu=zu, zd=zd, gamma_u=gamma_u, gamma_d=gamma_d)
+        if has_phi:
+            self.state.update(phi=phi, gamma=gamma)
+        return x
+
+    # ---- dense extraction helper (tests) -----------------------------------------------
+    def dense(self, op, T=None, dtype=np.float64):
+        """Dense (T*N, T*N) matrix of a (B,T,N,1)->(B,T,N,1) operator by applying it to identity
+        columns (one per batch entry)."""
+        T = self.T if T is None else T
+        n = T * self.N
+        eye = np.eye(n, dtype=dtype).reshape(n, T, self.N, 1)
+        return op(eye).reshape(n, n).T

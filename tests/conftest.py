@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "mixed-graph-admm_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def g4_meta():
+    return load_golden("g4_meta.npz")
+
+
+@pytest.fixture(scope="session")
+def g4_solves():
+    return load_golden("g4_solves.npz")
+
+
+def admm_info_from(meta):
+    return {k: float(meta[k]) for k in ("rho", "rho_u", "rho_d", "mu_u", "mu_d1", "mu_d2")}
+
+
+def has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False

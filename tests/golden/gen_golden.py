@@ -1,0 +1,367 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by IMPORTING AND RUNNING the reference.
+
+Run only in the authoring container (the reference is mounted read-only at /root/reference and
+never travels to the GPU box):
+
+    cd /tmp && MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/gen_golden.py
+
+Nothing from the reference is copied: the script builds synthetic graph_info dicts, calls the
+reference's public functions (utils.k_nearest_neighbors, ADMM.ADMM_algorithm(...).combined_loop,
+CG_solver, apply_op_*, ...) and stores inputs + outputs as small .npz files (data only).
+
+Fixture groups:
+  g1_tables_*   neighbour tables and weight tables            (utils.py:156-258)
+  g2_ops_*      dense matrices of every operator / LHS         (ADMM.py:138-228, 371-399)
+  g3_cg_*       CG_solver runs: x, iteration count, alpha/beta (ADMM.py:329-368)
+  g4_solve_*    full combined_loop runs + history              (ADMM.py:511-648)
+  g5_batched    8 single-sample solves stacked                 (batched-parity definition, Q6)
+  g6_kats       small literal known-answer vectors             (notebook / __main__ KATs)
+"""
+import contextlib
+import io
+import math
+import os
+import random
+import sys
+
+import numpy as np
+
+REF = os.environ.get("MGADMM_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+
+import pandas as pd  # noqa: E402
+import torch  # noqa: E402
+
+with contextlib.redirect_stdout(io.StringIO()):
+    import utils as ref_utils  # noqa: E402
+    import ADMM as ref_admm  # noqa: E402
+    import CG_script as ref_cg  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def make_graph(n, n_chords, seed, lo, hi, ring):
+    """Undirected edge list: a path (or ring) over n nodes plus random chords, lengths U(lo,hi)."""
+    rng = random.Random(seed)
+    edges = [(i, i + 1) for i in range(n - 1)]
+    if ring:
+        edges.append((n - 1, 0))
+    have = set(edges) | {(b, a) for a, b in edges}
+    while len(edges) < (n - 1 + int(ring)) + n_chords:
+        a, b = rng.randrange(n), rng.randrange(n)
+        if a == b or (a, b) in have:
+            continue
+        edges.append((a, b))
+        have.add((a, b)); have.add((b, a))
+    dist = [rng.uniform(lo, hi) for _ in edges]
+    return np.array(edges, dtype=np.int64), np.array(dist, dtype=np.float64)
+
+
+def graph_info(n, edges, dist):
+    df = pd.DataFrame({"from": edges[:, 0], "to": edges[:, 1], "cost": dist})
+    n_edges, u_edges, u_dist = ref_utils.physical_graph(df)
+    return {"n_nodes": n, "n_edges": n_edges, "u_edges": u_edges, "u_dist": u_dist}
+
+
+def admm_info(n, T=24):
+    r = math.sqrt(n / T)
+    return {"rho": 2 * r, "rho_u": 3 * r, "rho_d": 2 * r, "mu_u": 1, "mu_d1": 2, "mu_d2": 1}
+
+
+MODES = {
+    "knn": dict(use_kNN=True),
+    "physical": dict(use_kNN=False),
+    "line": dict(use_kNN=True, use_line_graph=True, skip_connection=1),
+    "skip3": dict(use_kNN=True, use_line_graph=True, skip_connection=3),
+}
+
+
+def build(gi, info, mode, k, sigma, ablation="None", t_in=12, T=24):
+    return quiet(ref_admm.ADMM_algorithm, gi, info, k=k, u_sigma=sigma, d_sigma=sigma,
+                 ablation=ablation, t_in=t_in, T=T, **MODES[mode])
+
+
+def dense_of(op, T, N, dtype=torch.float64):
+    n = T * N
+    eye = torch.eye(n, dtype=dtype).reshape(n, T, N, 1)
+    return op(eye).reshape(n, n).T.contiguous().numpy()
+
+
+def pad_lists(lst):
+    """list of 1-D tensors/lists of varying length -> (len, maxK) float64 array padded with NaN."""
+    rows = [np.asarray([float(v) for v in row], dtype=np.float64) for row in lst]
+    K = max((len(r) for r in rows), default=0)
+    out = np.full((len(rows), K), np.nan)
+    for i, r in enumerate(rows):
+        out[i, : len(r)] = r
+    return out
+
+
+def g1_tables(name, n, edges, dist, k, sigma):
+    gi = graph_info(n, edges, dist)
+    cl, dl = quiet(ref_utils.k_nearest_neighbors, n, gi["u_edges"], gi["u_dist"], k)
+    cl = cl.to(torch.int64)
+    u = quiet(ref_utils.undirected_graph_from_distance, cl, dl, u_sigma=sigma)
+    d = quiet(ref_utils.directed_graph_from_distance, cl, dl, d_sigma=sigma)
+    u_def = quiet(ref_utils.undirected_graph_from_distance, cl, dl)
+    d_def = quiet(ref_utils.directed_graph_from_distance, cl, dl)
+    pcl, pdl = quiet(ref_utils.connect_list, n, gi["u_edges"], gi["u_dist"])
+    pu = quiet(ref_utils.undirected_graph_from_distance, pcl, pdl, u_sigma=sigma)
+    pd_ = quiet(ref_utils.directed_graph_from_distance, pcl, pdl, d_sigma=sigma)
+    np.savez_compressed(
+        os.path.join(OUT, f"g1_tables_{name}.npz"), n=n, k=k, sigma=sigma, edges=edges, dist=dist,
+        u_edges=gi["u_edges"].numpy(), u_dist=gi["u_dist"].numpy(),
+        knn_cl=cl.numpy(), knn_dl=dl.numpy(), knn_u_ew=u.numpy(), knn_d_ew=d.numpy(),
+        knn_u_ew_defsigma=u_def.numpy(), knn_d_ew_defsigma=d_def.numpy(),
+        phys_cl=pcl.numpy(), phys_dl=pdl.numpy(), phys_u_ew=pu.numpy(), phys_d_ew=pd_.numpy())
+
+
+def g2_ops(n, edges, dist, k, sigma, T=6, t_in=3):
+    gi = graph_info(n, edges, dist)
+    for mode in MODES:
+        out = {}
+        for abl in ("None", "DGLR", "DGTV"):
+            a = build(gi, admm_info(n, T), mode, k, sigma, ablation=abl, t_in=t_in, T=T)
+            if abl == "None":
+                out["cl"] = a.connect_list.numpy()
+                out["u_ew"] = a.u_ew[0].numpy()
+                out["d_ew"] = (a.d_ew[0].numpy() if mode in ("knn", "physical") else a.d_ew.numpy())
+                for nm in ("Lu", "Ldr", "Ldr_T", "cLdr"):
+                    out[nm] = dense_of(getattr(a, "apply_op_" + nm), T, n)
+                out["LHS_zu"] = dense_of(a.LHS_zu, T, n)
+                out["LHS_zd"] = dense_of(a.LHS_zd, T, n)
+                torch.manual_seed(7)
+                m = (torch.rand(1, T, n, 1, dtype=torch.float64) >= 0.4).float()
+                out["mask"] = m.numpy()
+                out["LHS_x_mask_None"] = dense_of(lambda e: a.LHS_x(e, mask=m), T, n)
+                for key in ("rho", "rho_u", "rho_d", "mu_u", "mu_d1", "mu_d2"):
+                    out[key] = getattr(a, key)
+            out["LHS_x_" + abl] = dense_of(a.LHS_x, T, n)
+        np.savez_compressed(os.path.join(OUT, f"g2_ops_{mode}.npz"), T=T, t_in=t_in, n=n, **out)
+
+
+def g3_cg(n, edges, dist, k, sigma, T=6, t_in=3):
+    gi = graph_info(n, edges, dist)
+    out = {}
+    for mode in ("knn", "skip3"):
+        a = build(gi, admm_info(n, T), mode, k, sigma, t_in=t_in, T=T)
+        torch.manual_seed(11)
+        rhs = torch.randn(1, T, n, 1, dtype=torch.float64) * 10
+        x0 = torch.randn(1, T, n, 1, dtype=torch.float64)
+        m = (torch.rand(1, T, n, 1, dtype=torch.float64) >= 0.4).float()
+        out[f"{mode}_rhs"], out[f"{mode}_x0"], out[f"{mode}_mask"] = rhs.numpy(), x0.numpy(), m.numpy()
+        out[f"{mode}_cl"] = a.connect_list.numpy()
+        out[f"{mode}_u_ew"] = a.u_ew[0].numpy()
+        if mode == "knn":
+            out[f"{mode}_d_ew"] = a.d_ew[0].numpy()
+        for nm, fn, kw in (("x", a.LHS_x, {}), ("xmask", a.LHS_x, {"mask": m}), ("zu", a.LHS_zu, {}),
+                           ("zd", a.LHS_zd, {})):
+            for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+                kk = {q: v.to(dt) for q, v in kw.items()}
+                x, it, al, be = a.CG_solver(fn, rhs.to(dt), x0.to(dt), **kk)
+                out[f"{mode}_{nm}_{tag}_x"] = x.numpy()
+                out[f"{mode}_{nm}_{tag}_iters"] = it
+                out[f"{mode}_{nm}_{tag}_alpha"] = np.asarray([float(v) for v in al])
+                out[f"{mode}_{nm}_{tag}_beta"] = np.asarray([float(v) for v in be])
+        # x0=None path (zero start), zu operator
+        x, it, al, be = a.CG_solver(a.LHS_zu, rhs)
+        out[f"{mode}_zu_zero_x"], out[f"{mode}_zu_zero_iters"] = x.numpy(), it
+    for key in ("rho", "rho_u", "rho_d", "mu_u", "mu_d1", "mu_d2"):
+        out[key] = getattr(a, key)
+    np.savez_compressed(os.path.join(OUT, "g3_cg.npz"), T=T, t_in=t_in, n=n, **out)
+
+
+def run_solve(a, y, mask, iters):
+    a.max_ADMM_iter = iters
+    rec = {"cg": [], "phi": None}
+    orig_cg, orig_phi = a.CG_solver, a.phi_direct
+
+    def cg(*args, **kw):
+        r = orig_cg(*args, **kw)
+        rec["cg"].append(r[0])
+        return r
+
+    def phi(*args, **kw):
+        r = orig_phi(*args, **kw)
+        rec["phi"] = r
+        return r
+
+    a.CG_solver, a.phi_direct = cg, phi
+    x = quiet(a.combined_loop, y, mask=mask, print_info=False)
+    a.CG_solver, a.phi_direct = orig_cg, orig_phi
+    n_it = len(a.p_res_list)
+    per = len(rec["cg"]) // n_it
+    out = {
+        "x": x.numpy(), "n_iters": n_it,
+        "p_res": np.asarray(a.p_res_list, dtype=np.float64),
+        "d_res": np.asarray(a.d_res_list, dtype=np.float64),
+        "x_shift": np.asarray(a.x_shift_list, dtype=np.float64),
+        "dxps": torch.stack(a.delta_x_per_step).to(torch.float64).numpy(),
+        "GLR": np.asarray([float(v) for v in a.GLR_list]),
+        "DGTV": np.asarray([float(v) for v in a.DGTV_list]),
+        "DGLR": np.asarray([float(v) for v in a.DGLR_list]),
+        "recover": np.asarray(a.recover_list, dtype=np.float64),
+        "CG_iter_x": np.asarray(a.CG_iter_x), "CG_iter_zu": np.asarray(a.CG_iter_zu),
+        "CG_iter_zd": np.asarray(a.CG_iter_zd),
+        "alpha_x": pad_lists(a.alpha_x), "beta_x": pad_lists(a.beta_x),
+        "alpha_zu": pad_lists(a.alpha_zu), "beta_zu": pad_lists(a.beta_zu),
+        "zu": rec["cg"][-per + 1].numpy(),
+    }
+    if per == 3:
+        out["zd"] = rec["cg"][-1].numpy()
+        out["alpha_zd"] = pad_lists(a.alpha_zd)
+        out["beta_zd"] = pad_lists(a.beta_zd)
+    if rec["phi"] is not None:
+        out["phi"] = rec["phi"].numpy()
+    return out
+
+
+def synth_y(n, T, seed, dtype):
+    """Smooth synthetic traffic-like signal (B=1): level + daily sine + noise."""
+    g = torch.Generator().manual_seed(seed)
+    a = 50 + 350 * torch.rand(n, generator=g, dtype=torch.float64)
+    b = 20 + 60 * torch.rand(n, generator=g, dtype=torch.float64)
+    ph = 2 * math.pi * torch.rand(n, generator=g, dtype=torch.float64)
+    t = torch.arange(T, dtype=torch.float64)
+    x = a[None, :] + b[None, :] * torch.sin(2 * math.pi * t[:, None] / 48 + ph[None, :])
+    x = x + 5 * torch.randn(T, n, generator=g, dtype=torch.float64)
+    return x.reshape(1, T, n, 1).to(dtype)
+
+
+def g4_solves(n, edges, dist, k, sigma, T=24, t_in=12):
+    gi = graph_info(n, edges, dist)
+    info = admm_info(n, T)
+    meta = dict(n=n, k=k, sigma=sigma, T=T, t_in=t_in, edges=edges, dist=dist, **info)
+    base = build(gi, info, "knn", k, sigma)
+    meta.update(knn_cl=base.connect_list.numpy(), knn_dl=base.dist_list.numpy(),
+                knn_u_ew=base.u_ew[0].numpy(), knn_d_ew=base.d_ew[0].numpy())
+    phys = build(gi, info, "physical", k, sigma)
+    meta.update(phys_cl=phys.connect_list.numpy(), phys_u_ew=phys.u_ew[0].numpy(),
+                phys_d_ew=phys.d_ew[0].numpy())
+    full = synth_y(n, T, 3, torch.float64)
+    torch.manual_seed(42)                                   # utils.py:128-129
+    mask = (torch.rand_like(full) >= 0.4).float()
+    meta.update(x_true=full.numpy(), mask=mask.numpy())
+    np.savez_compressed(os.path.join(OUT, "g4_meta.npz"), **meta)
+
+    cases = []
+    for mode in ("knn", "line", "skip3"):
+        for abl in ("None", "DGTV", "DGLR", "UT"):
+            for task in ("pred", "mask"):
+                for tag in ("f64", "f32"):
+                    cases.append((mode, abl, task, tag, 5))
+    for mode in ("knn", "line", "skip3"):
+        for task in ("pred", "mask"):
+            for tag in ("f64", "f32"):
+                cases.append((mode, "None", task, tag, 50))
+    for abl in ("DGTV", "DGLR", "UT"):
+        cases.append(("knn", abl, "pred", "f64", 50))
+    cases.append(("physical", "None", "pred", "f64", 5))
+    cases.append(("physical", "None", "pred", "f32", 5))
+    allout = {}
+    for mode, abl, task, tag, iters in cases:
+        dt = torch.float64 if tag == "f64" else torch.float32
+        a = build(gi, info, mode, k, sigma, ablation=abl)
+        if task == "pred":
+            y, m = full[:, :t_in].to(dt), None
+        else:
+            m = mask.clone()                      # float32 mask like utils.py:129
+            y = (full * mask).to(dt)
+            if dt == torch.float32:
+                m = m.to(dt)
+        res = run_solve(a, y, m, iters)
+        key = f"{mode}-{abl}-{task}-{tag}-{iters}"
+        for kk, v in res.items():
+            allout[f"{key}/{kk}"] = v
+        print(key, "CG", res["CG_iter_x"][-1], res["CG_iter_zu"][-1],
+              "pri", res["p_res"][-1], file=sys.stderr)
+    np.savez_compressed(os.path.join(OUT, "g4_solves.npz"), **allout)
+
+
+def g5_batched(n, edges, dist, k, sigma, T=24, t_in=12, B=8, iters=10):
+    gi = graph_info(n, edges, dist)
+    info = admm_info(n, T)
+    ys, xs, hist = [], [], []
+    for b in range(B):
+        y = synth_y(n, T, 100 + b, torch.float64)[:, :t_in]
+        a = build(gi, info, "knn", k, sigma)
+        res = run_solve(a, y, None, iters)
+        ys.append(y.numpy()); xs.append(res["x"])
+        hist.append(res)
+    out = {"y": np.concatenate(ys, 0), "x": np.concatenate(xs, 0), "iters": iters}
+    for key in ("p_res", "d_res", "x_shift", "GLR", "DGTV", "DGLR", "recover", "CG_iter_x",
+                "CG_iter_zu", "CG_iter_zd", "zu", "zd", "phi"):
+        out[key] = np.stack([h[key] for h in hist], 0)
+    np.savez_compressed(os.path.join(OUT, "g5_batched.npz"), **out)
+
+
+def g6_kats():
+    out = {}
+    # CG_script.py __main__ KAT
+    A = np.array([[4, 1], [1, 3]], dtype=float)
+    b = np.array([1, 2], dtype=float)
+    x, it = ref_cg.conjugate_gradient(A, b)
+    out["cg_A"], out["cg_b"], out["cg_x"], out["cg_iters"] = A, b, x, it
+    # utils.py __main__ KAT
+    edges = torch.tensor([[0, 1], [1, 2], [2, 3], [3, 2], [2, 1], [1, 0]], dtype=torch.int)
+    dists = torch.tensor([1, 2, 3, 3, 2, 1])
+    cl, dl = quiet(ref_utils.connect_list, 4, edges, dists)
+    out["cl4_edges"], out["cl4_dists"] = edges.numpy(), dists.numpy()
+    out["cl4_cl"], out["cl4_dl"] = cl.numpy(), dl.numpy()
+    # line-graph operator KATs (directed_graph.ipynb): T=5, x=[1..5] on every node
+    gi = graph_info(3, np.array([[0, 1], [1, 2]]), np.array([1.0, 2.0]))
+    info = {"rho": 2, "rho_u": 1, "rho_d": 1, "mu_u": 1, "mu_d1": 1, "mu_d2": 1}
+    x = torch.arange(1, 6, dtype=torch.float64).reshape(1, 5, 1, 1).repeat(1, 1, 3, 1)
+    for skip in (1, 2):
+        a = quiet(ref_admm.ADMM_algorithm, gi, info, use_kNN=True, k=1, u_sigma=5, d_sigma=5, t_in=3,
+                  T=5, use_line_graph=True, skip_connection=skip)
+        out[f"line{skip}_Ldr"] = a.apply_op_Ldr(x).numpy()
+        out[f"line{skip}_LdrT"] = a.apply_op_Ldr_T(x).numpy()
+        out[f"line{skip}_d_ew"] = a.d_ew.numpy()
+        out[f"line{skip}_time_list"] = a.time_list.numpy()
+        if skip == 1:
+            out["line1_phi"] = a.phi_direct(x, torch.zeros_like(x)).numpy()
+    out["line_x"] = x.numpy()
+    # initial_guess KAT
+    y = torch.tensor([1.0, 3.0, 5.0]).reshape(1, 3, 1, 1)
+    out["ig_y32"] = y.numpy()
+    out["ig_x32"] = ref_admm.initial_guess(y, 3, 6).numpy()
+    out["ig_x64"] = ref_admm.initial_guess(y.double(), 3, 6).numpy()
+    torch.manual_seed(5)
+    yy = torch.rand(2, 12, 4, 2, dtype=torch.float64) * 100
+    out["ig_rand_y"] = yy.numpy()
+    out["ig_rand_x"] = ref_admm.initial_guess(yy, 12, 24).numpy()
+    # B=1: the reference's `w * t + b` broadcast (ADMM.py:802) only works for B=1 (or B==T)
+    full = torch.rand(1, 24, 4, 2, dtype=torch.float64) * 100
+    m = (torch.rand_like(full) >= 0.4).float()
+    out["ii_y"], out["ii_mask"] = (full * m).numpy(), m.numpy()
+    out["ii_x"] = quiet(ref_admm.initial_interpolation, full * m, m).numpy()
+    out["ii_x32"] = quiet(ref_admm.initial_interpolation, (full * m).float(), m).numpy()
+    np.savez_compressed(os.path.join(OUT, "g6_kats.npz"), **out)
+
+
+def main():
+    e12, d12 = make_graph(12, 3, seed=0, lo=1.0, hi=10.0, ring=True)
+    e30, d30 = make_graph(30, 8, seed=1, lo=3.0, hi=600.0, ring=False)
+    g1_tables("small", 12, e12, d12, k=3, sigma=5.0)
+    g1_tables("pems", 30, e30, d30, k=4, sigma=50.0)
+    g2_ops(12, e12, d12, k=3, sigma=5.0)
+    g3_cg(12, e12, d12, k=3, sigma=5.0)
+    g4_solves(30, e30, d30, k=4, sigma=50.0)
+    g5_batched(30, e30, d30, k=4, sigma=50.0)
+    g6_kats()
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
