@@ -1,0 +1,778 @@
+// Solver engine: host-side orchestration of the ADMM loop of reference ADMM.py:511-648 over the
+// streaming HIP kernels (stream_kernels.h), plus the C ABI of include/mgadmm.h.
+#include <math.h>
+#include <cmath>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <type_traits>
+
+#include "common.h"
+#include "stream_kernels.h"
+
+namespace {
+
+struct LhsDef {
+    int kind;  // 0 diagonal only, 1 cLdr = Ldr^T Ldr, 2 Lu
+    int hth;   // include the observation operator H^T H
+    double c1, c2;
+};
+
+enum VecId {
+    V_XA, V_XB, V_ZUA, V_ZUB, V_ZDA, V_ZDB, V_PHIA, V_PHIB, V_GAM, V_GU, V_GD, V_Y, V_MASK,
+    V_R, V_P, V_Q, V_AP, V_RHS, V_TMP, V_IO0, V_IO1, V_COUNT
+};
+
+constexpr int LAG = 2;          // CG iterations enqueued ahead of the host's convergence check
+constexpr int NRED_MAX = 6;
+constexpr int PROF_POOL = 32768;
+
+template <typename S>
+struct Engine : EngineBase {
+    mgadmm_solver* sv;
+    mgadmm_graph* g;
+    mgadmm_params p;
+    int T, N, Bmax, Bp_max;
+    hipStream_t st = nullptr;
+
+    S* vec[V_COUNT] = {nullptr};
+    S* vec_pool = nullptr;
+    size_t vec_elems = 0;
+    S* partials = nullptr;
+    size_t partials_elems = 0;
+    // CG scalars
+    S *d_rr = nullptr, *d_alpha = nullptr, *d_beta = nullptr, *d_alpha_hist = nullptr, *d_beta_hist = nullptr;
+    int *d_active = nullptr, *d_iters_tmp = nullptr, *d_nact = nullptr, *d_nonfinite = nullptr;
+    // history
+    double *d_ps = nullptr, *d_hist = nullptr, *d_dxps = nullptr, *d_dxpart = nullptr, *d_hist_ps = nullptr;
+    size_t hist_ps_elems = 0;
+    int* d_cg_iters = nullptr;
+    int max_admm_alloc = 0, max_cg_alloc = 0;
+    // pinned host
+    int* h_nact = nullptr;
+    double* h_row = nullptr;
+    int* h_flag = nullptr;
+    hipEvent_t ev_ring[LAG + 1] = {nullptr};
+    int want_blocks = 4096;
+    int64_t ws_bytes = 0;
+    // profiling
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_tag;
+    size_t prof_used = 0;
+    int64_t prof_count[MGADMM_NPROF] = {0};
+    double prof_bytes[MGADMM_NPROF] = {0};
+
+    explicit Engine(mgadmm_solver* s) : sv(s), g(s->g), p(s->p), T(s->g->T), N(s->g->N), Bmax(s->Bmax) {}
+
+    ~Engine() override {
+        (void)hipSetDevice(g->device);
+        auto fr = [](void* q) { if (q) (void)hipFree(q); };
+        fr(vec_pool); fr(partials); fr(d_rr); fr(d_alpha); fr(d_beta); fr(d_alpha_hist); fr(d_beta_hist);
+        fr(d_active); fr(d_iters_tmp); fr(d_nact); fr(d_nonfinite); fr(d_ps); fr(d_hist); fr(d_dxps);
+        fr(d_dxpart); fr(d_hist_ps); fr(d_cg_iters);
+        if (h_nact) (void)hipHostFree(h_nact);
+        if (h_row) (void)hipHostFree(h_row);
+        if (h_flag) (void)hipHostFree(h_flag);
+        for (auto& e : ev_ring) if (e) (void)hipEventDestroy(e);
+        for (auto& e : prof_ev) (void)hipEventDestroy(e);
+    }
+
+    // ---------------------------------------------------------------- geometry
+    Geom make_geom(int B) const {
+        Geom q;
+        q.T = T; q.N = N; q.B = B;
+        int vecw;
+        if (sizeof(S) == 4) vecw = B >= 192 ? 4 : (B >= 96 ? 2 : 1);
+        else vecw = B >= 96 ? 2 : 1;
+        const int cw = 64 * vecw;
+        q.VEC = vecw;
+        q.Bp = (B + cw - 1) / cw * cw;
+        q.CH = q.Bp / cw;
+        long per = 8L * T * q.CH;
+        int m = (int)((want_blocks + per - 1) / per);
+        int m_max = N / 64;
+        if (m_max < 1) m_max = 1;
+        if (m > m_max) m = m_max;
+        if (m < 1) m = 1;
+        q.NBX = m;
+        const int slots = 8 * m;
+        q.RB = (N + slots - 1) / slots;
+        q.NBLK = (N + q.RB - 1) / q.RB;
+        q.P = T * 8 * q.NBX;
+        q.grid = 8 * q.NBX * T * q.CH;
+        return q;
+    }
+
+    int ensure_partials(const Geom& q) {
+        size_t need = (size_t)NRED_MAX * q.P * q.Bp;
+        if (need <= partials_elems) return MGADMM_OK;
+        MG_HIP(hipStreamSynchronize(st));
+        if (partials) MG_HIP(hipFree(partials));
+        partials = nullptr;
+        MG_HIP(hipMalloc(&partials, need * sizeof(S)));
+        ws_bytes += (int64_t)(need - partials_elems) * sizeof(S);
+        partials_elems = need;
+        return MGADMM_OK;
+    }
+
+    int init() override {
+        MG_HIP(hipSetDevice(g->device));
+        if (const char* e = getenv("MGADMM_WANT_BLOCKS")) want_blocks = std::max(64, atoi(e));
+        Geom q = make_geom(Bmax);
+        Bp_max = q.Bp;
+        // Bp for smaller batches never exceeds Bp_max rounded to 256
+        Bp_max = std::max(Bp_max, ((Bmax + 63) / 64) * 64);
+        vec_elems = (size_t)T * N * Bp_max;
+        MG_HIP(hipMalloc(&vec_pool, vec_elems * V_COUNT * sizeof(S)));
+        ws_bytes += (int64_t)vec_elems * V_COUNT * sizeof(S);
+        for (int i = 0; i < V_COUNT; ++i) vec[i] = vec_pool + vec_elems * i;
+        MG_HIP(hipMalloc(&d_rr, Bp_max * sizeof(S)));
+        MG_HIP(hipMalloc(&d_alpha, Bp_max * sizeof(S)));
+        MG_HIP(hipMalloc(&d_beta, Bp_max * sizeof(S)));
+        MG_HIP(hipMalloc(&d_active, Bp_max * sizeof(int)));
+        MG_HIP(hipMalloc(&d_iters_tmp, Bp_max * sizeof(int)));
+        MG_HIP(hipMalloc(&d_nonfinite, sizeof(int)));
+        MG_HIP(hipMemset(d_nonfinite, 0, sizeof(int)));
+        MG_HIP(hipMalloc(&d_ps, sizeof(double) * MGADMM_NMETRIC * Bp_max));
+        const int nbk = (N + 63) / 64;
+        MG_HIP(hipMalloc(&d_dxpart, sizeof(double) * T * nbk));
+        MG_HIP(hipHostMalloc(&h_row, sizeof(double) * (MGADMM_NMETRIC + 1)));
+        MG_HIP(hipHostMalloc(&h_flag, sizeof(int) * 4));
+        for (auto& e : ev_ring) MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        MG_TRY(alloc_iter_dependent());
+        return MGADMM_OK;
+    }
+
+    int alloc_iter_dependent() {
+        auto fr = [](void* q) { if (q) (void)hipFree(q); };
+        if (p.max_cg_iter > max_cg_alloc) {
+            fr(d_nact); fr(d_alpha_hist); fr(d_beta_hist);
+            if (h_nact) (void)hipHostFree(h_nact);
+            d_nact = nullptr; d_alpha_hist = d_beta_hist = nullptr; h_nact = nullptr;
+            max_cg_alloc = p.max_cg_iter;
+            MG_HIP(hipMalloc(&d_nact, sizeof(int) * max_cg_alloc));
+            MG_HIP(hipMalloc(&d_alpha_hist, sizeof(S) * (size_t)max_cg_alloc * Bp_max));
+            MG_HIP(hipMalloc(&d_beta_hist, sizeof(S) * (size_t)max_cg_alloc * Bp_max));
+            MG_HIP(hipHostMalloc(&h_nact, sizeof(int) * max_cg_alloc));
+        }
+        if (p.max_admm_iter > max_admm_alloc) {
+            fr(d_hist); fr(d_dxps); fr(d_cg_iters);
+            d_hist = d_dxps = nullptr; d_cg_iters = nullptr;
+            max_admm_alloc = p.max_admm_iter;
+            MG_HIP(hipMalloc(&d_hist, sizeof(double) * (size_t)max_admm_alloc * MGADMM_NMETRIC));
+            MG_HIP(hipMalloc(&d_dxps, sizeof(double) * (size_t)max_admm_alloc * T));
+            MG_HIP(hipMalloc(&d_cg_iters, sizeof(int) * (size_t)max_admm_alloc * 3 * Bp_max));
+        }
+        return MGADMM_OK;
+    }
+
+    int set_params(const mgadmm_params& np) override {
+        MG_REQUIRE(np.dtype == p.dtype, "set_params: dtype cannot change after solver_create");
+        MG_REQUIRE(np.t_in >= 1 && np.t_in <= T, "set_params: t_in out of range");
+        MG_REQUIRE(np.max_cg_iter >= 1 && np.max_admm_iter >= 1, "set_params: iteration limits must be >= 1");
+        MG_REQUIRE(np.ablation >= 0 && np.ablation <= 3, "set_params: bad ablation");
+        p = np;
+        sv->p = np;
+        MG_HIP(hipSetDevice(g->device));
+        return alloc_iter_dependent();
+    }
+
+    int64_t workspace_bytes() const override { return ws_bytes; }
+    int path_for(int) const override { return MGADMM_PATH_STREAM; }
+
+    // ---------------------------------------------------------------- profiling
+    int prof_begin() override {
+        MG_HIP(hipSetDevice(g->device));
+        if (prof_ev.empty()) {
+            prof_ev.resize(2 * PROF_POOL);
+            for (auto& e : prof_ev) MG_HIP(hipEventCreate(&e));
+            prof_tag.resize(PROF_POOL);
+        }
+        prof_used = 0;
+        for (int i = 0; i < MGADMM_NPROF; ++i) { prof_count[i] = 0; prof_bytes[i] = 0; }
+        prof_on = true;
+        return MGADMM_OK;
+    }
+    int prof_end(int64_t* counts, double* total_ms, double* bytes) override {
+        prof_on = false;
+        MG_HIP(hipDeviceSynchronize());
+        double ms[MGADMM_NPROF] = {0};
+        int64_t timed[MGADMM_NPROF] = {0};
+        for (size_t i = 0; i < prof_used; ++i) {
+            float f = 0;
+            MG_HIP(hipEventElapsedTime(&f, prof_ev[2 * i], prof_ev[2 * i + 1]));
+            ms[prof_tag[i]] += f;
+            timed[prof_tag[i]]++;
+        }
+        for (int i = 0; i < MGADMM_NPROF; ++i) {
+            // launches past the event pool are counted but not timed: scale bytes to the timed share
+            counts[i] = timed[i];
+            total_ms[i] = ms[i];
+            bytes[i] = prof_count[i] ? prof_bytes[i] * ((double)timed[i] / (double)prof_count[i]) : 0.0;
+        }
+        return MGADMM_OK;
+    }
+    inline bool prof_open(int tag, double bytes) {
+        if (!prof_on) return false;
+        prof_count[tag]++;
+        prof_bytes[tag] += bytes;
+        if (tag == 3 || prof_used >= (size_t)PROF_POOL) return false;
+        prof_tag[prof_used] = tag;
+        (void)hipEventRecord(prof_ev[2 * prof_used], st);
+        return true;
+    }
+    inline void prof_close() {
+        (void)hipEventRecord(prof_ev[2 * prof_used + 1], st);
+        prof_used++;
+    }
+
+    double pass_bytes(const Geom& q, int passes) const { return (double)passes * q.B * (double)T * N * sizeof(S); }
+    double csr_bytes(const OpDesc& op) const {
+        if (op.kind != OPK_SPATIAL) return 0.0;
+        int nnz = 0;
+        if (op.rowptr == g->Wu.rowptr) nnz = g->Wu.nnz;
+        else if (op.rowptr == g->Wd.rowptr) nnz = g->Wd.nnz;
+        else nnz = g->WdT.nnz;
+        return (double)nnz * 8 + (double)(N + 1) * 4;
+    }
+
+    // ---------------------------------------------------------------- launch helpers
+    template <int VEC, class Epi>
+    int rows_v(const Geom& q, const OpDesc& op, const S* in, const Epi& epi, const int* live, int tag, double bytes) {
+        const bool timed = prof_open(tag, bytes);
+        hipLaunchKernelGGL((k_rows<S, VEC, Epi>), dim3(q.grid), dim3(256), 0, st, q, op, op.rowptr, op.col, op.val, op.band_w, in,
+                           epi, partials, live);
+        if (timed) prof_close();
+        MG_HIP(hipGetLastError());
+        return MGADMM_OK;
+    }
+
+    template <template <typename, int> class E, class... A>
+    int rows(const Geom& q, const OpDesc& op, const S* in, const int* live, int tag, int passes, A... a) {
+        const double bytes = pass_bytes(q, passes) + csr_bytes(op);
+        switch (q.VEC) {
+            case 1: return rows_v<1>(q, op, in, E<S, 1>{a...}, live, tag, bytes);
+            case 2: return rows_v<2>(q, op, in, E<S, 2>{a...}, live, tag, bytes);
+            case 4:
+                if constexpr (sizeof(S) == 4) return rows_v<4>(q, op, in, E<S, 4>{a...}, live, tag, bytes);
+        }
+        mg_set_error("rows: unsupported VEC %d", q.VEC);
+        return MGADMM_ERR_UNSUPPORTED;
+    }
+
+    template <int NRED, class Fin>
+    int reduce(const Geom& q, const Fin& fin, const int* live) {
+        prof_open(3, 0);
+        hipLaunchKernelGGL((k_reduce<S, NRED, Fin>), dim3(q.Bp / 64), dim3(1024), 0, st, partials, q.P, q.Bp, fin, live);
+        MG_HIP(hipGetLastError());
+        return MGADMM_OK;
+    }
+
+    static OpDesc op_none() {
+        OpDesc o{};
+        o.kind = OPK_NONE;
+        return o;
+    }
+
+    int pack(const Geom& q, const void* src, int Ts, S* dst) {
+        dim3 grid((N + 63) / 64, T, q.Bp / 64);
+        prof_open(3, 0);
+        hipLaunchKernelGGL((k_pack<S>), grid, dim3(256), 0, st, T, Ts, N, q.B, q.Bp, g->d_perm, (const S*)src, dst);
+        MG_HIP(hipGetLastError());
+        return MGADMM_OK;
+    }
+    int unpack(const Geom& q, const S* src, void* dst) {
+        dim3 grid((N + 63) / 64, T, q.Bp / 64);
+        prof_open(3, 0);
+        hipLaunchKernelGGL((k_unpack<S>), grid, dim3(256), 0, st, T, N, q.B, q.Bp, g->d_perm, src, (S*)dst);
+        MG_HIP(hipGetLastError());
+        return MGADMM_OK;
+    }
+    int fill(S* dst, size_t n, S v) {
+        hipLaunchKernelGGL((k_fill<S>), dim3(1024), dim3(256), 0, st, dst, n, v);
+        MG_HIP(hipGetLastError());
+        return MGADMM_OK;
+    }
+    size_t velems(const Geom& q) const { return (size_t)T * N * q.Bp; }
+
+    int check_B(int B, const char* who) {
+        MG_REQUIRE(B >= 1 && B <= Bmax, "%s: batch %d outside [1, max_batch=%d]", who, B, Bmax);
+        MG_HIP(hipSetDevice(g->device));
+        return MGADMM_OK;
+    }
+
+    LhsDef lhs_def(int which) const {
+        switch (which) {
+            case MGADMM_LHS_X:
+                if (p.ablation == MGADMM_ABL_NONE) return {1, 1, (p.rho_u + p.rho_d) / 2, p.rho / 2};
+                if (p.ablation == MGADMM_ABL_DGLR) return {1, 1, p.rho_u / 2, p.rho / 2};
+                return {0, 1, (p.rho_u + p.rho_d) / 2, 0.0};
+            case MGADMM_LHS_ZU: return {2, 0, p.rho_u / 2, p.mu_u};
+            default: return {1, 0, p.rho_d / 2, p.mu_d2};
+        }
+    }
+
+    // ---------------------------------------------------------------- operators (internal layout)
+    int op_store(const Geom& q, const OpDesc& op, const S* in, S* out, int tag = 2) {
+        return rows<EpiStore>(q, op, in, nullptr, tag, 2, out);
+    }
+    int cldr(const Geom& q, const S* in, S* out) {
+        MG_TRY(op_store(q, g->op_ldr(), in, vec[V_Q]));
+        return op_store(q, g->op_ldrt(), vec[V_Q], out);
+    }
+
+    // Ap = A p for an LhsDef; dot partial lands in partials[0]
+    int lhs_apply(const Geom& q, const LhsDef& d, const S* pin, const S* mask, S* Ap, const int* live) {
+        if (d.kind == 1) {
+            MG_TRY(rows<EpiStore>(q, g->op_ldr(), pin, live, 0, 2, vec[V_Q]));
+            return rows<EpiLhs>(q, g->op_ldrt(), vec[V_Q], live, 0, 3, pin, mask, Ap, d.hth, p.t_in, (S)d.c1, (S)d.c2);
+        }
+        if (d.kind == 2)
+            return rows<EpiLhs>(q, g->op_lu(), pin, live, 0, 2, (const S*)nullptr, mask, Ap, d.hth, p.t_in, (S)d.c1, (S)d.c2);
+        return rows<EpiLhs>(q, op_none(), pin, live, 1, 2, (const S*)nullptr, mask, Ap, d.hth, p.t_in, (S)d.c1, (S)0);
+    }
+
+    // ---------------------------------------------------------------- CG (ADMM.py:329-368)
+    // rhs, x0, xout: internal layout.  iters_dev: int[Bp] destination for the per-sample counts.
+    int cg_internal(const Geom& q, const LhsDef& d, const S* rhs, const S* x0, const S* mask, S* xout, int* iters_dev,
+                    bool record, int* n_iter_launched = nullptr) {
+        CgScalars<S> c;
+        c.rr = d_rr; c.alpha = d_alpha; c.beta = d_beta; c.active = d_active; c.iters = iters_dev; c.n_active = d_nact;
+        c.alpha_hist = record ? d_alpha_hist : nullptr;
+        c.beta_hist = record ? d_beta_hist : nullptr;
+        c.nonfinite = d_nonfinite;
+        const int K = p.max_cg_iter;
+        MG_HIP(hipMemsetAsync(d_nact, 0, sizeof(int) * K, st));
+        if (record) {
+            MG_TRY(fill(d_alpha_hist, (size_t)K * q.Bp, (S)NAN));
+            MG_TRY(fill(d_beta_hist, (size_t)K * q.Bp, (S)NAN));
+        }
+        S *r = vec[V_R], *pp = vec[V_P], *Ap = vec[V_AP];
+        // r = rhs - A x0 ; p = r ; x = x0
+        if (d.kind == 1) {
+            MG_TRY(rows<EpiStore>(q, g->op_ldr(), x0, nullptr, 2, 2, vec[V_Q]));
+            MG_TRY(rows<EpiCgInit>(q, g->op_ldrt(), vec[V_Q], nullptr, 2, 6, x0, rhs, mask, r, pp, xout, d.hth, p.t_in,
+                                   (S)d.c1, (S)d.c2));
+        } else if (d.kind == 2) {
+            MG_TRY(rows<EpiCgInit>(q, g->op_lu(), x0, nullptr, 2, 5, (const S*)nullptr, rhs, mask, r, pp, xout, d.hth,
+                                   p.t_in, (S)d.c1, (S)d.c2));
+        } else {
+            MG_TRY(rows<EpiCgInit>(q, op_none(), x0, nullptr, 1, 5, (const S*)nullptr, rhs, mask, r, pp, xout, d.hth,
+                                   p.t_in, (S)d.c1, (S)0));
+        }
+        MG_TRY((reduce<1>(q, FinCgInit<S>{c, q.B}, nullptr)));
+        int k = 0;
+        for (; k < K; ++k) {
+            const int* live = k == 0 ? nullptr : d_nact + (k - 1);
+            MG_TRY(lhs_apply(q, d, pp, nullptr, Ap, live));                  // Ap = A p (no mask: quirk Q2)
+            MG_TRY((reduce<1>(q, FinCgAlpha<S>{c, k, q.Bp}, live)));
+            MG_TRY(rows<EpiCgUpdate>(q, op_none(), pp, live, 1, 6, (const S*)d_alpha, xout, r, (const S*)Ap));
+            MG_TRY((reduce<1>(q, FinCgBeta<S>{c, k, q.Bp, p.cg_tol}, live)));
+            MG_TRY(rows<EpiPUpdate>(q, op_none(), r, live, 1, 3, (const S*)d_beta, pp));
+            MG_HIP(hipMemcpyAsync(h_nact + k, d_nact + k, sizeof(int), hipMemcpyDeviceToHost, st));
+            MG_HIP(hipEventRecord(ev_ring[k % (LAG + 1)], st));
+            if (k >= LAG) {
+                MG_HIP(hipEventSynchronize(ev_ring[(k - LAG) % (LAG + 1)]));
+                if (h_nact[k - LAG] == 0) { ++k; break; }
+            }
+        }
+        if (n_iter_launched) *n_iter_launched = k;
+        return MGADMM_OK;
+    }
+
+    // ---------------------------------------------------------------- fine-grained ABI entry points
+    int apply(int op, const void* x, void* y, int B, hipStream_t s) override {
+        MG_TRY(check_B(B, "apply"));
+        MG_REQUIRE(x && y, "apply: null pointer");
+        st = s;
+        Geom q = make_geom(B);
+        MG_TRY(ensure_partials(q));
+        MG_TRY(pack(q, x, T, vec[V_IO0]));
+        switch (op) {
+            case MGADMM_OP_LU: MG_TRY(op_store(q, g->op_lu(), vec[V_IO0], vec[V_IO1])); break;
+            case MGADMM_OP_LDR: MG_TRY(op_store(q, g->op_ldr(), vec[V_IO0], vec[V_IO1])); break;
+            case MGADMM_OP_LDRT: MG_TRY(op_store(q, g->op_ldrt(), vec[V_IO0], vec[V_IO1])); break;
+            case MGADMM_OP_CLDR: MG_TRY(cldr(q, vec[V_IO0], vec[V_IO1])); break;
+            default: mg_set_error("apply: bad op %d", op); return MGADMM_ERR_INVALID;
+        }
+        return unpack(q, vec[V_IO1], y);
+    }
+
+    int lhs(int which, const void* x, const void* mask, void* y, int B, hipStream_t s) override {
+        MG_TRY(check_B(B, "lhs"));
+        MG_REQUIRE(x && y, "lhs: null pointer");
+        MG_REQUIRE(which >= 0 && which <= 2, "lhs: bad operator id %d", which);
+        MG_REQUIRE(!(which == MGADMM_LHS_ZD && p.ablation == MGADMM_ABL_DGLR), "lhs: LHS_zd is undefined for ablation 'DGLR' (ADMM.py:392-399)");
+        st = s;
+        Geom q = make_geom(B);
+        MG_TRY(ensure_partials(q));
+        MG_TRY(pack(q, x, T, vec[V_IO0]));
+        const S* m = nullptr;
+        if (mask && which == MGADMM_LHS_X) {
+            MG_TRY(pack(q, mask, T, vec[V_MASK]));
+            m = vec[V_MASK];
+        }
+        MG_TRY(lhs_apply(q, lhs_def(which), vec[V_IO0], m, vec[V_IO1], nullptr));
+        return unpack(q, vec[V_IO1], y);
+    }
+
+    int phi_direct(const void* x, const void* gamma, void* phi, int B, hipStream_t s) override {
+        MG_TRY(check_B(B, "phi_direct"));
+        MG_REQUIRE(x && gamma && phi, "phi_direct: null pointer");
+        st = s;
+        Geom q = make_geom(B);
+        MG_TRY(ensure_partials(q));
+        MG_TRY(pack(q, x, T, vec[V_IO0]));
+        MG_TRY(pack(q, gamma, T, vec[V_TMP]));
+        MG_TRY(rows<EpiPhiDirect>(q, g->op_ldr(), vec[V_IO0], nullptr, 2, 4, (const S*)vec[V_TMP], vec[V_IO1], (S)p.rho,
+                                  (S)(p.mu_d1 / p.rho)));
+        return unpack(q, vec[V_IO1], phi);
+    }
+
+    int guess_internal(const Geom& q, const S* ypad, S* x) {
+        // float32 time moments of ADMM.py:772-775
+        float tm = 0, t2m = 0;
+        for (int t = 0; t < p.t_in; ++t) { tm += (float)t; t2m += (float)t * (float)t; }
+        tm /= (float)p.t_in;
+        t2m /= (float)p.t_in;
+        const float den = t2m - tm * tm;
+        dim3 grid((N + 3) / 4, q.Bp / 64);
+        hipLaunchKernelGGL((k_initial_guess<S>), grid, dim3(256), 0, st, T, p.t_in, N, q.Bp, (S)tm, (S)den, ypad, x);
+        MG_HIP(hipGetLastError());
+        return MGADMM_OK;
+    }
+    int interp_internal(const Geom& q, const S* y, const S* mask, int mask_f32, S* x) {
+        dim3 grid((N + 3) / 4, q.Bp / 64);
+        if (mask_f32 && sizeof(S) == 8)
+            hipLaunchKernelGGL((k_initial_interp<S, true>), grid, dim3(256), 0, st, T, N, q.Bp, q.B, y, mask, x, d_nonfinite);
+        else
+            hipLaunchKernelGGL((k_initial_interp<S, false>), grid, dim3(256), 0, st, T, N, q.Bp, q.B, y, mask, x, d_nonfinite);
+        MG_HIP(hipGetLastError());
+        return MGADMM_OK;
+    }
+
+    int initial_guess(const void* y, void* x, int B, hipStream_t s) override {
+        MG_TRY(check_B(B, "initial_guess"));
+        MG_REQUIRE(x && y, "initial_guess: null pointer");
+        st = s;
+        Geom q = make_geom(B);
+        MG_TRY(pack(q, y, p.t_in, vec[V_Y]));
+        MG_TRY(guess_internal(q, vec[V_Y], vec[V_IO1]));
+        return unpack(q, vec[V_IO1], x);
+    }
+
+    int initial_interpolation(const void* y, const void* mask, int mask_f32, void* x, int B, hipStream_t s) override {
+        MG_TRY(check_B(B, "initial_interpolation"));
+        MG_REQUIRE(x && y && mask, "initial_interpolation: null pointer");
+        st = s;
+        Geom q = make_geom(B);
+        MG_TRY(pack(q, y, T, vec[V_Y]));
+        MG_TRY(pack(q, mask, T, vec[V_MASK]));
+        MG_TRY(interp_internal(q, vec[V_Y], vec[V_MASK], mask_f32, vec[V_IO1]));
+        return unpack(q, vec[V_IO1], x);
+    }
+
+    int fetch_hist(const S* dev, size_t n, double* out, size_t B, size_t Bp, size_t K) {
+        // dev: [K][Bp] -> out: [K][B] doubles
+        std::vector<S> tmp(n);
+        MG_HIP(hipMemcpyAsync(tmp.data(), dev, n * sizeof(S), hipMemcpyDeviceToHost, st));
+        MG_HIP(hipStreamSynchronize(st));
+        for (size_t k = 0; k < K; ++k)
+            for (size_t b = 0; b < B; ++b) out[k * B + b] = (double)tmp[k * Bp + b];
+        return MGADMM_OK;
+    }
+
+    int cg(int which, const void* rhs, const void* x0, const void* mask, void* x, int32_t* iters, double* alpha,
+           double* beta, int B, hipStream_t s) override {
+        MG_TRY(check_B(B, "cg"));
+        MG_REQUIRE(rhs && x && iters, "cg: null pointer");
+        MG_REQUIRE(which >= 0 && which <= 2, "cg: bad operator id %d", which);
+        MG_REQUIRE(!(which == MGADMM_LHS_ZD && p.ablation == MGADMM_ABL_DGLR), "cg: LHS_zd is undefined for ablation 'DGLR'");
+        st = s;
+        Geom q = make_geom(B);
+        MG_TRY(ensure_partials(q));
+        MG_HIP(hipMemsetAsync(d_nonfinite, 0, sizeof(int), st));
+        MG_TRY(pack(q, rhs, T, vec[V_RHS]));
+        if (x0) MG_TRY(pack(q, x0, T, vec[V_IO0]));
+        else MG_HIP(hipMemsetAsync(vec[V_IO0], 0, velems(q) * sizeof(S), st));
+        const S* m = nullptr;
+        if (mask && which == MGADMM_LHS_X) {
+            MG_TRY(pack(q, mask, T, vec[V_MASK]));
+            m = vec[V_MASK];
+        }
+        MG_TRY(cg_internal(q, lhs_def(which), vec[V_RHS], vec[V_IO0], m, vec[V_IO1], d_iters_tmp, true));
+        MG_TRY(unpack(q, vec[V_IO1], x));
+        MG_HIP(hipMemcpyAsync(iters, d_iters_tmp, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+        MG_HIP(hipMemcpyAsync(h_flag, d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+        MG_HIP(hipStreamSynchronize(st));
+        const size_t K = p.max_cg_iter;
+        if (alpha) MG_TRY(fetch_hist(d_alpha_hist, K * q.Bp, alpha, B, q.Bp, K));
+        if (beta) MG_TRY(fetch_hist(d_beta_hist, K * q.Bp, beta, B, q.Bp, K));
+        if (h_flag[0]) {
+            mg_set_error("cg: non-finite residual met");
+            return MGADMM_ERR_NONFINITE;
+        }
+        return MGADMM_OK;
+    }
+
+    // ---------------------------------------------------------------- combined_loop (ADMM.py:511-648)
+    int solve(const void* y, const void* mask, int mask_f32, int B, void* x_out, const mgadmm_state* state_out,
+              mgadmm_history* hist, hipStream_t s) override {
+        MG_TRY(check_B(B, "solve"));
+        MG_REQUIRE(y && x_out, "solve: null pointer");
+        st = s;
+        const Geom q = make_geom(B);
+        MG_TRY(ensure_partials(q));
+        const size_t ne = velems(q);
+        const int abl = p.ablation;
+        const bool has_phi = (abl == MGADMM_ABL_NONE || abl == MGADMM_ABL_DGLR);
+        const bool has_zd = (abl != MGADMM_ABL_DGLR);
+        const int max_it = p.max_admm_iter;
+        const bool record = p.record_cg_coeffs && hist && hist->cg_alpha && hist->cg_beta;
+
+        if (hist && hist->metrics_per_sample) {
+            size_t need = (size_t)max_it * MGADMM_NMETRIC * B;
+            if (need > hist_ps_elems) {
+                if (d_hist_ps) MG_HIP(hipFree(d_hist_ps));
+                d_hist_ps = nullptr;
+                MG_HIP(hipMalloc(&d_hist_ps, need * sizeof(double)));
+                hist_ps_elems = need;
+            }
+        }
+        MG_HIP(hipMemsetAsync(d_nonfinite, 0, sizeof(int), st));
+        MG_HIP(hipMemsetAsync(d_ps, 0, sizeof(double) * MGADMM_NMETRIC * q.Bp, st));
+        MG_HIP(hipMemsetAsync(d_cg_iters, 0, sizeof(int) * (size_t)max_it * 3 * q.Bp, st));
+
+        int xc = V_XA, xn = V_XB, zuc = V_ZUA, zun = V_ZUB, zdc = V_ZDA, zdn = V_ZDB, phc = V_PHIA, phn = V_PHIB;
+        const S* m = nullptr;
+        if (mask) {
+            MG_TRY(pack(q, y, T, vec[V_Y]));
+            MG_TRY(pack(q, mask, T, vec[V_MASK]));
+            m = vec[V_MASK];
+            MG_TRY(interp_internal(q, vec[V_Y], m, mask_f32, vec[xc]));
+        } else {
+            MG_TRY(pack(q, y, p.t_in, vec[V_Y]));
+            MG_TRY(guess_internal(q, vec[V_Y], vec[xc]));
+        }
+        MG_TRY(fill(vec[V_GU], ne, (S)0.1));
+        MG_TRY(fill(vec[V_GD], ne, (S)0.1));
+        if (has_phi) {
+            MG_TRY(fill(vec[V_GAM], ne, (S)0.1));
+            MG_TRY(op_store(q, g->op_ldr(), vec[xc], vec[phc]));
+        }
+        MG_HIP(hipMemcpyAsync(vec[zuc], vec[xc], ne * sizeof(S), hipMemcpyDeviceToDevice, st));
+        MG_HIP(hipMemcpyAsync(vec[zdc], vec[xc], ne * sizeof(S), hipMemcpyDeviceToDevice, st));
+
+        const S rho = (S)p.rho, rho_u = (S)p.rho_u, rho_d = (S)p.rho_d;
+        int n_done = 0;
+        int rc_final = MGADMM_OK;
+        for (int it = 0; it < max_it; ++it) {
+            // ---- RHS_x (ADMM.py:556-564)
+            if (has_phi) {
+                MG_TRY(rows<EpiLin2>(q, op_none(), vec[V_GAM], nullptr, 3, 3, (const S*)vec[phc], vec[V_TMP], (S)1, rho));
+                MG_TRY(rows<EpiRhsX>(q, g->op_ldrt(), vec[V_TMP], nullptr, 2, has_zd ? 7 : 5, (const S*)vec[zuc],
+                                     (const S*)vec[zdc], (const S*)vec[V_GU], (const S*)vec[V_GD], (const S*)vec[V_Y],
+                                     vec[V_RHS], rho_u, rho_d, 1, has_zd ? 1 : 0));
+            } else {
+                MG_TRY(rows<EpiRhsX>(q, op_none(), vec[zuc], nullptr, 3, 6, (const S*)vec[zuc], (const S*)vec[zdc],
+                                     (const S*)vec[V_GU], (const S*)vec[V_GD], (const S*)vec[V_Y], vec[V_RHS], rho_u,
+                                     rho_d, 0, 1));
+            }
+            // ---- x, zu, zd CG solves (ADMM.py:571-592)
+            int* it_base = d_cg_iters + (size_t)it * 3 * q.Bp;
+            MG_TRY(cg_internal(q, lhs_def(MGADMM_LHS_X), vec[V_RHS], vec[xc], m, vec[xn], it_base, record));
+            if (record) MG_TRY(save_coeffs(q, hist, it, 0, B));
+            MG_TRY(rows<EpiLin2>(q, op_none(), vec[V_GU], nullptr, 3, 3, (const S*)vec[xn], vec[V_RHS], (S)0.5, (S)(p.rho_u / 2)));
+            MG_TRY(cg_internal(q, lhs_def(MGADMM_LHS_ZU), vec[V_RHS], vec[zuc], nullptr, vec[zun], it_base + q.Bp, record));
+            if (record) MG_TRY(save_coeffs(q, hist, it, 1, B));
+            if (has_zd) {
+                MG_TRY(rows<EpiLin2>(q, op_none(), vec[V_GD], nullptr, 3, 3, (const S*)vec[xn], vec[V_RHS], (S)0.5, (S)(p.rho_d / 2)));
+                MG_TRY(cg_internal(q, lhs_def(MGADMM_LHS_ZD), vec[V_RHS], vec[zdc], nullptr, vec[zdn], it_base + 2 * q.Bp, record));
+                if (record) MG_TRY(save_coeffs(q, hist, it, 2, B));
+            }
+            const S* zd_now = has_zd ? vec[zdn] : vec[zdc];
+            // ---- dual updates + Laplacian-free residuals (ADMM.py:595-597, 612-636)
+            MG_TRY(rows<EpiDual>(q, op_none(), vec[xn], nullptr, 3, has_zd ? 11 : 6, (const S*)vec[xc], (const S*)vec[zun],
+                                 (const S*)vec[zuc], zd_now, (const S*)vec[zdc], (const S*)vec[V_Y], m, vec[V_GU],
+                                 vec[V_GD], rho_u, rho_d, has_zd ? 1 : 0, p.t_in));
+            {
+                FinMetrics<6> f{d_ps, q.Bp, {MGADMM_M_XSHIFT, MGADMM_M_PRI_ZU, MGADMM_M_DUAL_ZU, has_zd ? MGADMM_M_PRI_ZD : -1,
+                                            has_zd ? MGADMM_M_DUAL_ZD : -1, MGADMM_M_RECOVER}};
+                MG_TRY((reduce<6>(q, f, nullptr)));
+            }
+            // ---- phi prox, gamma update, Ldr-based residuals and regularisers (ADMM.py:600-606, 627-637)
+            MG_TRY(rows<EpiPhi>(q, g->op_ldr(), vec[xn], nullptr, 2, has_phi ? 5 : 1, (const S*)vec[phc], vec[phn], vec[V_GAM],
+                                rho, (S)(p.mu_d1 / p.rho), has_phi ? 1 : 0));
+            {
+                FinMetrics<4> f{d_ps, q.Bp, {has_phi ? MGADMM_M_PRI_PHI : -1, has_phi ? MGADMM_M_DUAL_PHI : -1,
+                                            has_phi ? MGADMM_M_DGTV : -1, has_zd ? MGADMM_M_DGLR : -1}};
+                MG_TRY((reduce<4>(q, f, nullptr)));
+            }
+            MG_TRY(rows<EpiDot>(q, g->op_lu(), vec[xn], nullptr, 2, 1));
+            {
+                FinMetrics<1> f{d_ps, q.Bp, {MGADMM_M_GLR}};
+                MG_TRY((reduce<1>(q, f, nullptr)));
+            }
+            const int nbk = (N + 63) / 64;
+            hipLaunchKernelGGL((k_dxps<S>), dim3(T * nbk), dim3(256), 0, st, T, N, q.Bp, B, nbk, (const S*)vec[xn],
+                               (const S*)vec[xc], d_dxpart);
+            hipLaunchKernelGGL(k_dxps_final, dim3((T + 63) / 64), dim3(64), 0, st, T, nbk, (const double*)d_dxpart,
+                               d_dxps + (size_t)it * T);
+            hipLaunchKernelGGL(k_batch_metrics, dim3(MGADMM_NMETRIC), dim3(256), 0, st, (const double*)d_ps, q.Bp, B,
+                               d_hist + (size_t)it * MGADMM_NMETRIC,
+                               (hist && hist->metrics_per_sample) ? d_hist_ps + (size_t)it * MGADMM_NMETRIC * B : nullptr);
+            MG_HIP(hipGetLastError());
+            std::swap(xc, xn);
+            std::swap(zuc, zun);
+            if (has_zd) std::swap(zdc, zdn);
+            if (has_phi) std::swap(phc, phn);
+            n_done = it + 1;
+            if (p.check_stop) {
+                MG_HIP(hipMemcpyAsync(h_row, d_hist + (size_t)it * MGADMM_NMETRIC, sizeof(double) * MGADMM_NMETRIC,
+                                      hipMemcpyDeviceToHost, st));
+                MG_HIP(hipMemcpyAsync(h_flag, d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+                MG_HIP(hipStreamSynchronize(st));
+                bool finite = h_flag[0] == 0;
+                for (int k = 0; k < MGADMM_NMETRIC; ++k) finite = finite && std::isfinite(h_row[k]);
+                if (!finite) { rc_final = MGADMM_ERR_NONFINITE; break; }
+                double pri = h_row[MGADMM_M_PRI_ZU], dual = h_row[MGADMM_M_DUAL_ZU];
+                if (has_phi) { pri = std::max(pri, h_row[MGADMM_M_PRI_PHI]); dual = std::max(dual, h_row[MGADMM_M_DUAL_PHI]); }
+                if (has_zd) { pri = std::max(pri, h_row[MGADMM_M_PRI_ZD]); dual = std::max(dual, h_row[MGADMM_M_DUAL_ZD]); }
+                if (pri < p.admm_tol && dual < p.admm_tol) break;      // ADMM.py:645-646
+            }
+        }
+        // ---- results
+        MG_TRY(unpack(q, vec[xc], x_out));
+        if (state_out) {
+            if (state_out->zu) MG_TRY(unpack(q, vec[zuc], state_out->zu));
+            if (state_out->zd) MG_TRY(unpack(q, vec[zdc], state_out->zd));
+            if (state_out->phi && has_phi) MG_TRY(unpack(q, vec[phc], state_out->phi));
+            if (state_out->gamma && has_phi) MG_TRY(unpack(q, vec[V_GAM], state_out->gamma));
+            if (state_out->gamma_u) MG_TRY(unpack(q, vec[V_GU], state_out->gamma_u));
+            if (state_out->gamma_d) MG_TRY(unpack(q, vec[V_GD], state_out->gamma_d));
+        }
+        if (hist) {
+            hist->n_iters = n_done;
+            if (hist->metrics)
+                MG_HIP(hipMemcpyAsync(hist->metrics, d_hist, sizeof(double) * (size_t)n_done * MGADMM_NMETRIC, hipMemcpyDeviceToHost, st));
+            if (hist->delta_x_per_step)
+                MG_HIP(hipMemcpyAsync(hist->delta_x_per_step, d_dxps, sizeof(double) * (size_t)n_done * T, hipMemcpyDeviceToHost, st));
+            if (hist->metrics_per_sample)
+                MG_HIP(hipMemcpyAsync(hist->metrics_per_sample, d_hist_ps, sizeof(double) * (size_t)n_done * MGADMM_NMETRIC * B,
+                                      hipMemcpyDeviceToHost, st));
+            if (hist->cg_iters) {
+                std::vector<int> tmp((size_t)n_done * 3 * q.Bp);
+                MG_HIP(hipMemcpyAsync(tmp.data(), d_cg_iters, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost, st));
+                MG_HIP(hipStreamSynchronize(st));
+                for (size_t r = 0; r < (size_t)n_done * 3; ++r)
+                    memcpy(hist->cg_iters + r * B, tmp.data() + r * q.Bp, sizeof(int) * B);
+            }
+        }
+        MG_HIP(hipMemcpyAsync(h_flag, d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+        MG_HIP(hipStreamSynchronize(st));
+        if (rc_final == MGADMM_OK && h_flag[0]) rc_final = MGADMM_ERR_NONFINITE;
+        if (rc_final == MGADMM_OK && hist && hist->metrics) {
+            for (size_t k = 0; k < (size_t)n_done * MGADMM_NMETRIC; ++k)
+                if (!std::isfinite(hist->metrics[k])) rc_final = MGADMM_ERR_NONFINITE;
+        }
+        if (rc_final == MGADMM_ERR_NONFINITE) mg_set_error("solve: NaN/Inf met in the iterates (cf. the asserts of ADMM.py:534-606)");
+        return rc_final;
+    }
+
+    int save_coeffs(const Geom& q, mgadmm_history* hist, int it, int which, int B) {
+        const size_t K = p.max_cg_iter;
+        double* a = hist->cg_alpha + ((size_t)it * 3 + which) * K * B;
+        double* b = hist->cg_beta + ((size_t)it * 3 + which) * K * B;
+        MG_TRY(fetch_hist(d_alpha_hist, K * q.Bp, a, B, q.Bp, K));
+        return fetch_hist(d_beta_hist, K * q.Bp, b, B, q.Bp, K);
+    }
+};
+
+}  // namespace
+
+EngineBase* mg_make_engine_f32(mgadmm_solver* s) { return new Engine<float>(s); }
+EngineBase* mg_make_engine_f64(mgadmm_solver* s) { return new Engine<double>(s); }
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int mgadmm_solver_create(mgadmm_graph* g, const mgadmm_params* p, int32_t max_batch, mgadmm_solver** out) {
+    MG_REQUIRE(g && p && out, "solver_create: null argument");
+    MG_REQUIRE(max_batch >= 1, "solver_create: max_batch must be >= 1");
+    MG_REQUIRE(p->dtype == MGADMM_F32 || p->dtype == MGADMM_F64, "solver_create: bad dtype %d", p->dtype);
+    MG_REQUIRE(p->t_in >= 1 && p->t_in <= g->T, "solver_create: t_in %d outside [1, T=%d]", p->t_in, g->T);
+    MG_REQUIRE(p->ablation >= 0 && p->ablation <= 3, "solver_create: ablation should be one of None, DGTV, DGLR, UT");
+    MG_REQUIRE(p->max_cg_iter >= 1 && p->max_admm_iter >= 1, "solver_create: iteration limits must be >= 1");
+    mgadmm_solver* s = new mgadmm_solver();
+    s->g = g;
+    s->p = *p;
+    s->Bmax = max_batch;
+    s->eng = p->dtype == MGADMM_F32 ? mg_make_engine_f32(s) : mg_make_engine_f64(s);
+    int rc = s->eng->init();
+    if (rc != MGADMM_OK) {
+        delete s->eng;
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return MGADMM_OK;
+}
+
+int mgadmm_solver_destroy(mgadmm_solver* s) {
+    if (!s) return MGADMM_OK;
+    delete s->eng;
+    delete s;
+    return MGADMM_OK;
+}
+
+int mgadmm_solver_set_params(mgadmm_solver* s, const mgadmm_params* p) {
+    MG_REQUIRE(s && p, "set_params: null argument");
+    return s->eng->set_params(*p);
+}
+
+int64_t mgadmm_solver_workspace_bytes(const mgadmm_solver* s) { return s ? s->eng->workspace_bytes() : 0; }
+int mgadmm_solver_path(const mgadmm_solver* s, int32_t B) { return s ? s->eng->path_for(B) : MGADMM_ERR_INVALID; }
+
+int mgadmm_apply(mgadmm_solver* s, int32_t op, const void* x, void* y, int32_t B, void* stream) {
+    MG_REQUIRE(s, "apply: null solver");
+    return s->eng->apply(op, x, y, B, (hipStream_t)stream);
+}
+int mgadmm_lhs(mgadmm_solver* s, int32_t which, const void* x, const void* mask, void* y, int32_t B, void* stream) {
+    MG_REQUIRE(s, "lhs: null solver");
+    return s->eng->lhs(which, x, mask, y, B, (hipStream_t)stream);
+}
+int mgadmm_phi_direct(mgadmm_solver* s, const void* x, const void* gamma, void* phi, int32_t B, void* stream) {
+    MG_REQUIRE(s, "phi_direct: null solver");
+    return s->eng->phi_direct(x, gamma, phi, B, (hipStream_t)stream);
+}
+int mgadmm_initial_guess(mgadmm_solver* s, const void* y, void* x, int32_t B, void* stream) {
+    MG_REQUIRE(s, "initial_guess: null solver");
+    return s->eng->initial_guess(y, x, B, (hipStream_t)stream);
+}
+int mgadmm_initial_interpolation(mgadmm_solver* s, const void* y, const void* mask, int32_t mask_is_f32, void* x,
+                                 int32_t B, void* stream) {
+    MG_REQUIRE(s, "initial_interpolation: null solver");
+    return s->eng->initial_interpolation(y, mask, mask_is_f32, x, B, (hipStream_t)stream);
+}
+int mgadmm_cg(mgadmm_solver* s, int32_t which, const void* rhs, const void* x0, const void* mask, void* x, int32_t* iters,
+              double* alpha, double* beta, int32_t B, void* stream) {
+    MG_REQUIRE(s, "cg: null solver");
+    return s->eng->cg(which, rhs, x0, mask, x, iters, alpha, beta, B, (hipStream_t)stream);
+}
+int mgadmm_solve(mgadmm_solver* s, const void* y, const void* mask, int32_t mask_is_f32, int32_t B, void* x_out,
+                 const mgadmm_state* state_out, mgadmm_history* hist, void* stream) {
+    MG_REQUIRE(s, "solve: null solver");
+    return s->eng->solve(y, mask, mask_is_f32, B, x_out, state_out, hist, (hipStream_t)stream);
+}
+int mgadmm_prof_begin(mgadmm_solver* s) {
+    MG_REQUIRE(s, "prof_begin: null solver");
+    return s->eng->prof_begin();
+}
+int mgadmm_prof_end(mgadmm_solver* s, int64_t* counts, double* total_ms, double* bytes) {
+    MG_REQUIRE(s && counts && total_ms && bytes, "prof_end: null argument");
+    return s->eng->prof_end(counts, total_ms, bytes);
+}
+
+}  // extern "C"

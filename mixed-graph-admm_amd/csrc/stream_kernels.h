@@ -1,0 +1,733 @@
+// Streaming kernels of the ADMM hot path for gfx950 (wave64).
+//
+// Device layout ("batch-innermost"): a signal (B,T,N) is held as V[t][i][b], b contiguous, padded to
+// Bp columns (a multiple of 64*VEC).  One wavefront owns one graph node row (t,i) over 64*VEC
+// consecutive batch columns, so
+//   * the node's own row and every neighbour row of the sparse Laplacian are read as one fully
+//     coalesced 256 B .. 1 KiB segment per wave instruction (VEC*4 B per lane);
+//   * the CSR row (rowptr/col/val) is wave-uniform and is fetched through the scalar cache;
+//   * the per-sample CG dot products are per-LANE running sums -- no cross-lane traffic until the
+//     fixed-order cross-wave / cross-workgroup reduction (bitwise repeatable, no atomics).
+// blockIdx -> work mapping is XCD-aware: consecutive blockIdx values are dealt round-robin over the 8
+// XCDs, so block b works on node-block range (b & 7): each XCD sweeps its own eighth of the node
+// range of time slice t and then the same eighth of slice t+1, which keeps the rows a time-shifted
+// operator (Ldr / Ldr^T) re-reads in that XCD's L2 / the Infinity Cache.
+#pragma once
+#include "common.h"
+
+template <typename S, int V>
+struct alignas(sizeof(S) * V) Vec {
+    S v[V];
+};
+
+template <typename S, int V>
+__device__ __forceinline__ Vec<S, V> ldv(const S* p) {
+    return *reinterpret_cast<const Vec<S, V>*>(p);
+}
+template <typename S, int V>
+__device__ __forceinline__ void stv(S* p, const Vec<S, V>& x) {
+    *reinterpret_cast<Vec<S, V>*>(p) = x;
+}
+
+struct Geom {
+    int T, N, B, Bp;
+    int VEC, CH;         // columns per lane; column chunks of 64*VEC
+    int RB, NBLK, NBX;   // rows per workgroup, node-blocks per time slice, node-block slots per XCD
+    int P;               // partial-sum rows per column = T * 8 * NBX
+    int grid;            // 8 * NBX * T * CH workgroups
+};
+
+// ---------------------------------------------------------------------------------------------
+// l = op(in) at row (t,i) for this lane's VEC columns.
+//   SPATIAL: l = selfc(t) * in[t][i] - sum_e val[e] * in[t+shift][col[e]]      (Lu, Ldr, Ldr^T)
+//   BAND   : l = selfc(t) * in[t][i] - sum_s w[.][s] * in[t -/+ (1+s)][i]      (line graph)
+//   NONE   : l = in[t][i]
+// Reference: ADMM.py:138-223.
+// ---------------------------------------------------------------------------------------------
+template <typename S, int VEC>
+__device__ __forceinline__ Vec<S, VEC> op_apply(const Geom& g, const OpDesc& op, const int* __restrict__ rowptr,
+                                                const int* __restrict__ colidx, const float* __restrict__ val,
+                                                const float* __restrict__ band_w, const S* __restrict__ in, int t,
+                                                int i, int col0, const Vec<S, VEC>& self) {
+    Vec<S, VEC> sum;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) sum.v[v] = S(0);
+    S selfc = S(1);
+    if (op.kind == OPK_SPATIAL) {
+        const int ts = t + op.shift;
+        if (op.self_mode == SELF_LDR) selfc = (t >= 1) ? S(1) : S(0);
+        else if (op.self_mode == SELF_LDRT) selfc = (t > 0 || op.q1) ? S(1) : S(0);
+        if (ts >= 0 && ts < g.T) {
+            const S* base = in + (size_t)ts * g.N * g.Bp + col0;
+            const int e0 = rowptr[i], e1 = rowptr[i + 1];
+#pragma unroll 2
+            for (int e = e0; e < e1; ++e) {
+                const int c = colidx[e];
+                const S w = (S)val[e];
+                const Vec<S, VEC> nv = ldv<S, VEC>(base + (size_t)c * g.Bp);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) sum.v[v] += w * nv.v[v];
+            }
+        }
+    } else if (op.kind == OPK_BAND) {
+        if (op.band_dir < 0) {
+            selfc = (t >= 1) ? S(1) : S(0);
+            for (int s = 0; s < op.skip; ++s) {
+                const int ts = t - 1 - s;
+                if (ts < 0) break;
+                const S w = (S)band_w[t * op.skip + s];
+                const Vec<S, VEC> nv = ldv<S, VEC>(in + ((size_t)ts * g.N + i) * g.Bp + col0);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) sum.v[v] += w * nv.v[v];
+            }
+        } else {
+            selfc = (t > 0) ? S(1) : S(0);
+            for (int s = 0; s < op.skip; ++s) {
+                const int ts = t + 1 + s;
+                if (ts >= g.T) break;
+                const S w = (S)band_w[ts * op.skip + s];
+                const Vec<S, VEC> nv = ldv<S, VEC>(in + ((size_t)ts * g.N + i) * g.Bp + col0);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) sum.v[v] += w * nv.v[v];
+            }
+        }
+    }
+    Vec<S, VEC> l;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) l.v[v] = selfc * self.v[v] - sum.v[v];
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row kernel: every wave walks node rows of one (column chunk, time slice, node block); the epilogue
+// functor fuses the element-wise work of the caller (LHS combination, CG dot, prox, dual update, ...).
+// partials: [NRED][P][Bp] per-workgroup per-column partial sums (summed by k_reduce in fixed order).
+// live: optional device flag; a zero value makes the launch a no-op (speculatively enqueued CG
+// iterations after every sample has converged).
+// ---------------------------------------------------------------------------------------------
+template <typename S, int VEC, class Epi>
+__global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __restrict__ rowptr,
+                                              const int* __restrict__ colidx, const float* __restrict__ val,
+                                              const float* __restrict__ band_w, const S* __restrict__ in, Epi epi_in,
+                                              S* __restrict__ partials, const int* __restrict__ live) {
+    if (live != nullptr && *live == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int j = blockIdx.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int nbl = j % g.NBX;
+    j /= g.NBX;
+    const int t = j % g.T;
+    const int chunk = j / g.T;
+    const int nb = xcd * g.NBX + nbl;
+    const int col0 = (chunk * 64 + lane) * VEC;
+
+    Epi epi = epi_in;
+    epi.begin(col0);
+    constexpr int NR = Epi::NRED > 0 ? Epi::NRED : 1;
+    S acc[NR][VEC];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[r][v] = S(0);
+
+    const int n0 = nb * g.RB;
+    const int n1 = (nb < g.NBLK) ? min(g.N, n0 + g.RB) : n0;
+    for (int i = n0 + wave; i < n1; i += 4) {
+        const size_t off = ((size_t)t * g.N + i) * g.Bp + col0;
+        const Vec<S, VEC> self = ldv<S, VEC>(in + off);
+        const Vec<S, VEC> l = op_apply<S, VEC>(g, op, rowptr, colidx, val, band_w, in, t, i, col0, self);
+        epi.row(t, off, self, l, acc);
+    }
+
+    if (Epi::NRED > 0) {
+        __shared__ S sm[3][VEC][64];
+        const int p = (t * 8 + xcd) * g.NBX + nbl;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (wave > 0) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) sm[wave - 1][v][lane] = acc[r][v];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                Vec<S, VEC> o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o.v[v] = ((acc[r][v] + sm[0][v][lane]) + sm[1][v][lane]) + sm[2][v][lane];
+                stv<S, VEC>(partials + ((size_t)r * g.P + p) * g.Bp + col0, o);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------ epilogues
+template <typename S, int VEC>
+struct EpiStore {  // out = l
+    static constexpr int NRED = 0;
+    S* out;
+    __device__ void begin(int) {}
+    __device__ void row(int, size_t off, const Vec<S, VEC>&, const Vec<S, VEC>& l, S (*)[VEC]) { stv<S, VEC>(out + off, l); }
+};
+
+// Ap = HtH p + c1 p + c2 l ; acc0 += p.Ap       (LHS_x / LHS_zu / LHS_zd applied to the CG direction,
+// ADMM.py:349, 371-399).  p == nullptr: the gathered vector is p itself (Lu / diagonal case).
+template <typename S, int VEC>
+struct EpiLhs {
+    static constexpr int NRED = 1;
+    const S* p;
+    const S* mask;  // only for the stand-alone mgadmm_lhs entry point (LHS_x(x, mask))
+    S* Ap;
+    int hth, t_in;
+    S c1, c2;
+    __device__ void begin(int) {}
+    __device__ void row(int t, size_t off, const Vec<S, VEC>& self, const Vec<S, VEC>& l, S (*acc)[VEC]) {
+        const Vec<S, VEC> pv = p ? ldv<S, VEC>(p + off) : self;
+        Vec<S, VEC> d;
+        if (mask) d = ldv<S, VEC>(mask + off);
+        else {
+            const S dd = (hth && t < t_in) ? S(1) : S(0);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) d.v[v] = dd;
+        }
+        Vec<S, VEC> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            o.v[v] = d.v[v] * pv.v[v] + c1 * pv.v[v] + c2 * l.v[v];
+            acc[0][v] += pv.v[v] * o.v[v];
+        }
+        stv<S, VEC>(Ap + off, o);
+    }
+};
+
+// CG start: r = rhs - A x0 ; p = r ; x = x0 ; acc0 += r.r      (ADMM.py:339-347; `mask` only here, quirk Q2)
+template <typename S, int VEC>
+struct EpiCgInit {
+    static constexpr int NRED = 1;
+    const S* x0;    // nullptr: the gathered vector is x0 itself
+    const S* rhs;
+    const S* mask;  // nullptr: HtH = [t < t_in]
+    S *r, *p, *x;
+    int hth, t_in;
+    S c1, c2;
+    __device__ void begin(int) {}
+    __device__ void row(int t, size_t off, const Vec<S, VEC>& self, const Vec<S, VEC>& l, S (*acc)[VEC]) {
+        const Vec<S, VEC> xv = x0 ? ldv<S, VEC>(x0 + off) : self;
+        const Vec<S, VEC> bv = ldv<S, VEC>(rhs + off);
+        Vec<S, VEC> d;
+        if (mask) d = ldv<S, VEC>(mask + off);
+        else {
+            const S dd = (hth && t < t_in) ? S(1) : S(0);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) d.v[v] = dd;
+        }
+        Vec<S, VEC> rv;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const S ax = d.v[v] * xv.v[v] + c1 * xv.v[v] + c2 * l.v[v];
+            rv.v[v] = bv.v[v] - ax;
+            acc[0][v] += rv.v[v] * rv.v[v];
+        }
+        stv<S, VEC>(r + off, rv);
+        stv<S, VEC>(p + off, rv);
+        stv<S, VEC>(x + off, xv);
+    }
+};
+
+// x += alpha p ; r -= alpha Ap ; acc0 += r.r     (ADMM.py:352-355).  Gathered vector = p.
+template <typename S, int VEC>
+struct EpiCgUpdate {
+    static constexpr int NRED = 1;
+    const S* alpha;
+    S *x, *r;
+    const S* Ap;
+    S a[VEC];
+    __device__ void begin(int col0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a[v] = alpha[col0 + v];
+    }
+    __device__ void row(int, size_t off, const Vec<S, VEC>& pv, const Vec<S, VEC>&, S (*acc)[VEC]) {
+        Vec<S, VEC> xv = ldv<S, VEC>(x + off), rv = ldv<S, VEC>(r + off);
+        const Vec<S, VEC> av = ldv<S, VEC>(Ap + off);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            xv.v[v] = xv.v[v] + a[v] * pv.v[v];
+            rv.v[v] = rv.v[v] - a[v] * av.v[v];
+            acc[0][v] += rv.v[v] * rv.v[v];
+        }
+        stv<S, VEC>(x + off, xv);
+        stv<S, VEC>(r + off, rv);
+    }
+};
+
+// p = r + beta p     (ADMM.py:366).  Gathered vector = r.
+template <typename S, int VEC>
+struct EpiPUpdate {
+    static constexpr int NRED = 0;
+    const S* beta;
+    S* p;
+    S b[VEC];
+    __device__ void begin(int col0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) b[v] = beta[col0 + v];
+    }
+    __device__ void row(int, size_t off, const Vec<S, VEC>& rv, const Vec<S, VEC>&, S (*)[VEC]) {
+        Vec<S, VEC> pv = ldv<S, VEC>(p + off);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) pv.v[v] = rv.v[v] + b[v] * pv.v[v];
+        stv<S, VEC>(p + off, pv);
+    }
+};
+
+// out = a*in + b*w     (gamma + rho*phi ; gamma_u/2 + rho_u/2 x : ADMM.py:559, 579, 587)
+template <typename S, int VEC>
+struct EpiLin2 {
+    static constexpr int NRED = 0;
+    const S* w;
+    S* out;
+    S a, b;
+    __device__ void begin(int) {}
+    __device__ void row(int, size_t off, const Vec<S, VEC>& u, const Vec<S, VEC>&, S (*)[VEC]) {
+        const Vec<S, VEC> wv = ldv<S, VEC>(w + off);
+        Vec<S, VEC> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.v[v] = a * u.v[v] + b * wv.v[v];
+        stv<S, VEC>(out + off, o);
+    }
+};
+
+// RHS_x = [Ldr^T(gamma + rho phi)]/2 + (rho_u zu + rho_d zd)/2 - (gamma_u + gamma_d)/2 + Hty   (ADMM.py:556-564)
+template <typename S, int VEC>
+struct EpiRhsX {
+    static constexpr int NRED = 0;
+    const S *zu, *zd, *gu, *gd, *y;
+    S* out;
+    S rho_u, rho_d;
+    int use_l, use_zd;
+    __device__ void begin(int) {}
+    __device__ void row(int, size_t off, const Vec<S, VEC>&, const Vec<S, VEC>& l, S (*)[VEC]) {
+        const Vec<S, VEC> zuv = ldv<S, VEC>(zu + off), guv = ldv<S, VEC>(gu + off), yv = ldv<S, VEC>(y + off);
+        Vec<S, VEC> o;
+        if (use_zd) {
+            const Vec<S, VEC> zdv = ldv<S, VEC>(zd + off), gdv = ldv<S, VEC>(gd + off);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                o.v[v] = (rho_u * zuv.v[v] + rho_d * zdv.v[v]) / S(2) - (guv.v[v] + gdv.v[v]) / S(2) + yv.v[v];
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o.v[v] = rho_u * zuv.v[v] / S(2) - guv.v[v] / S(2) + yv.v[v];
+        }
+        if (use_l) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o.v[v] = l.v[v] / S(2) + o.v[v];
+        }
+        stv<S, VEC>(out + off, o);
+    }
+};
+
+// Dual updates of gamma_u, gamma_d (ADMM.py:595-597) fused with the residual norms that do not need a
+// Laplacian (ADMM.py:612-636).  Gathered vector = new x.
+// acc: 0 ||x-x_old||^2, 1 ||x-zu||^2, 2 ||zu-zu_old||^2, 3 ||x-zd||^2, 4 ||zd-zd_old||^2, 5 ||Hx-y||^2
+template <typename S, int VEC>
+struct EpiDual {
+    static constexpr int NRED = 6;
+    const S *xold, *zu, *zuold, *zd, *zdold, *y, *mask;
+    S *gu, *gd;
+    S rho_u, rho_d;
+    int has_zd, t_in;
+    __device__ void begin(int) {}
+    __device__ void row(int t, size_t off, const Vec<S, VEC>& x, const Vec<S, VEC>&, S (*acc)[VEC]) {
+        const Vec<S, VEC> xo = ldv<S, VEC>(xold + off), z = ldv<S, VEC>(zu + off), zo = ldv<S, VEC>(zuold + off);
+        Vec<S, VEC> g = ldv<S, VEC>(gu + off);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const S dx = x.v[v] - xo.v[v], pz = x.v[v] - z.v[v], dz = z.v[v] - zo.v[v];
+            acc[0][v] += dx * dx;
+            acc[1][v] += pz * pz;
+            acc[2][v] += dz * dz;
+            g.v[v] = g.v[v] + rho_u * pz;
+        }
+        stv<S, VEC>(gu + off, g);
+        if (has_zd) {
+            const Vec<S, VEC> zdv = ldv<S, VEC>(zd + off), zdo = ldv<S, VEC>(zdold + off);
+            Vec<S, VEC> gdv = ldv<S, VEC>(gd + off);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const S pz = x.v[v] - zdv.v[v], dz = zdv.v[v] - zdo.v[v];
+                acc[3][v] += pz * pz;
+                acc[4][v] += dz * dz;
+                gdv.v[v] = gdv.v[v] + rho_d * pz;
+            }
+            stv<S, VEC>(gd + off, gdv);
+        }
+        if (mask) {
+            const Vec<S, VEC> m = ldv<S, VEC>(mask + off), yv = ldv<S, VEC>(y + off);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const S e = x.v[v] * m.v[v] - yv.v[v];
+                acc[5][v] += e * e;
+            }
+        } else if (t < t_in) {
+            const Vec<S, VEC> yv = ldv<S, VEC>(y + off);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const S e = x.v[v] - yv.v[v];
+                acc[5][v] += e * e;
+            }
+        }
+    }
+};
+
+template <typename S>
+__device__ __forceinline__ S soft_thr(S s, S thr) {
+    const S u = fabs(s) - thr;
+    return (u > S(0)) ? (s > S(0) ? u : -u) : S(0);
+}
+
+// phi prox + gamma dual update (ADMM.py:401-408, 600-606) with l = Ldr x computed once, fused with
+// ||phi - Ldr x||^2, ||phi - phi_old||^2, ||Ldr x||_1 and sum (Ldr x)^2.  update == 0: metrics only.
+template <typename S, int VEC>
+struct EpiPhi {
+    static constexpr int NRED = 4;
+    const S* phi_old;
+    S* phi_new;
+    S* gamma;
+    S rho, thr;
+    int update;
+    __device__ void begin(int) {}
+    __device__ void row(int, size_t off, const Vec<S, VEC>&, const Vec<S, VEC>& l, S (*acc)[VEC]) {
+        if (update) {
+            const Vec<S, VEC> po = ldv<S, VEC>(phi_old + off);
+            Vec<S, VEC> g = ldv<S, VEC>(gamma + off), pn;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                pn.v[v] = soft_thr<S>(l.v[v] - g.v[v] / rho, thr);
+                const S d = pn.v[v] - l.v[v], dp = pn.v[v] - po.v[v];
+                g.v[v] = g.v[v] + rho * d;
+                acc[0][v] += d * d;
+                acc[1][v] += dp * dp;
+            }
+            stv<S, VEC>(phi_new + off, pn);
+            stv<S, VEC>(gamma + off, g);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            acc[2][v] += fabs(l.v[v]);
+            acc[3][v] += l.v[v] * l.v[v];
+        }
+    }
+};
+
+// stand-alone phi_direct(x, gamma)  (ADMM.py:401-408)
+template <typename S, int VEC>
+struct EpiPhiDirect {
+    static constexpr int NRED = 0;
+    const S* gamma;
+    S* phi;
+    S rho, thr;
+    __device__ void begin(int) {}
+    __device__ void row(int, size_t off, const Vec<S, VEC>&, const Vec<S, VEC>& l, S (*)[VEC]) {
+        const Vec<S, VEC> g = ldv<S, VEC>(gamma + off);
+        Vec<S, VEC> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.v[v] = soft_thr<S>(l.v[v] - g.v[v] / rho, thr);
+        stv<S, VEC>(phi + off, o);
+    }
+};
+
+// GLR: acc0 += x . Lu x     (ADMM.py:245-246)
+template <typename S, int VEC>
+struct EpiDot {
+    static constexpr int NRED = 1;
+    __device__ void begin(int) {}
+    __device__ void row(int, size_t, const Vec<S, VEC>& x, const Vec<S, VEC>& l, S (*acc)[VEC]) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[0][v] += x.v[v] * l.v[v];
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Fixed-order reduction of the per-workgroup partials + the per-sample scalar step that follows it.
+// One workgroup = 64 batch columns x 16 waves; wave w sums partial rows w, w+16, ...; wave 0 combines
+// the 16 sub-sums in order and runs Fin for its 64 columns.
+// ---------------------------------------------------------------------------------------------
+template <typename S, int NRED, class Fin>
+__global__ __launch_bounds__(1024) void k_reduce(const S* __restrict__ partials, int P, int Bp, Fin fin,
+                                                 const int* __restrict__ live) {
+    if (live != nullptr && *live == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    double s[NRED];
+#pragma unroll
+    for (int r = 0; r < NRED; ++r) s[r] = 0.0;
+    for (int p = wave; p < P; p += 16) {
+#pragma unroll
+        for (int r = 0; r < NRED; ++r) s[r] += (double)partials[((size_t)r * P + p) * Bp + c];
+    }
+    __shared__ double sm[15][NRED][64];
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < NRED; ++r) sm[wave - 1][r][lane] = s[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < 15; ++w)
+#pragma unroll
+            for (int r = 0; r < NRED; ++r) s[r] += sm[w][r][lane];
+        fin(c, s);
+    }
+}
+
+// CG scalars, one entry per batch column.
+template <typename S>
+struct CgScalars {
+    S* rr;         // r.r
+    S* alpha;
+    S* beta;
+    int* active;   // 1 while the sample still iterates
+    int* iters;    // iteration count at convergence, -1 otherwise
+    int* n_active; // [max_cg_iter] number of active samples after iteration k
+    S* alpha_hist; // [max_cg_iter][Bp] or nullptr
+    S* beta_hist;
+    int* nonfinite;
+};
+
+template <typename S>
+struct FinCgInit {
+    CgScalars<S> c;
+    int B;
+    __device__ void operator()(int col, const double* s) const {
+        c.rr[col] = (S)s[0];
+        c.active[col] = col < B ? 1 : 0;
+        c.iters[col] = -1;
+        c.alpha[col] = S(0);
+        c.beta[col] = S(0);
+    }
+};
+
+template <typename S>
+struct FinCgAlpha {  // alpha = r.r / p.Ap   (ADMM.py:350)
+    CgScalars<S> c;
+    int k, Bp;
+    __device__ void operator()(int col, const double* s) const {
+        const bool act = c.active[col] != 0;
+        const S a = act ? c.rr[col] / (S)s[0] : S(0);
+        c.alpha[col] = a;
+        if (c.alpha_hist) c.alpha_hist[(size_t)k * Bp + col] = act ? a : (S)NAN;
+    }
+};
+
+template <typename S>
+struct FinCgBeta {  // beta = rr'/rr ; convergence sqrt(rr') < tol ; (ADMM.py:355-362), per sample (Q6)
+    CgScalars<S> c;
+    int k, Bp;
+    double tol;
+    __device__ void operator()(int col, const double* s) const {
+        bool act = c.active[col] != 0;
+        S b = S(0);
+        if (act) {
+            const S rrn = (S)s[0];
+            b = rrn / c.rr[col];
+            c.rr[col] = rrn;
+            if (c.beta_hist) c.beta_hist[(size_t)k * Bp + col] = b;
+            if (!(fabs((double)rrn) <= 1.79e308)) {  // NaN / Inf: stop this sample, report
+                *c.nonfinite = 1;
+                c.active[col] = 0;
+                act = false;
+            } else if ((double)sqrt(rrn) < tol) {
+                c.iters[col] = k + 1;
+                c.active[col] = 0;
+                act = false;
+            }
+        } else if (c.beta_hist) {
+            c.beta_hist[(size_t)k * Bp + col] = (S)NAN;
+        }
+        c.beta[col] = act ? b : S(0);
+        const unsigned long long m = __ballot(act);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c.n_active[k], __popcll(m));
+    }
+};
+
+// per-sample metric sums -> ps[slot[r]][col]
+template <int NRED>
+struct FinMetrics {
+    double* ps;  // [MGADMM_NMETRIC][Bp]
+    int Bp;
+    int slot[NRED];
+    __device__ void operator()(int col, const double* s) const {
+#pragma unroll
+        for (int r = 0; r < NRED; ++r)
+            if (slot[r] >= 0) ps[(size_t)slot[r] * Bp + col] = s[r];
+    }
+};
+
+// whole-batch value of every metric for this ADMM iteration (fixed summation order over samples):
+// norms -> sqrt(sum_b), regularisers -> mean_b      (ADMM.py:612-637, 230-246)
+__global__ void k_batch_metrics(const double* __restrict__ ps, int Bp, int B, double* __restrict__ out,
+                                double* __restrict__ out_ps /* [NMETRIC][B] or nullptr */) {
+    const int m = blockIdx.x;
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (int c = threadIdx.x; c < B; c += 256) {
+        const double v = ps[(size_t)m * Bp + c];
+        s += v;
+        if (out_ps) out_ps[(size_t)m * B + c] = v;
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double tot = sm[0];
+        const bool is_mean = (m == MGADMM_M_GLR || m == MGADMM_M_DGTV || m == MGADMM_M_DGLR);
+        out[m] = is_mean ? tot / (double)B : sqrt(tot);
+    }
+}
+
+// delta_x_per_step: || mean_b (x - x_old) ||_2 over nodes, per time step (ADMM.py:614).
+// part[t][nbk]: sum over the 64 nodes of block nbk of (mean_b dx)^2.
+template <typename S>
+__global__ __launch_bounds__(256) void k_dxps(int T, int N, int Bp, int B, int NBK, const S* __restrict__ x,
+                                              const S* __restrict__ xold, double* __restrict__ part) {
+    const int t = blockIdx.x / NBK, nbk = blockIdx.x % NBK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i1 = min(N, (nbk + 1) * 64);
+    double a = 0.0;
+    for (int i = nbk * 64 + wave; i < i1; i += 4) {
+        const size_t off = ((size_t)t * N + i) * Bp;
+        double s = 0.0;
+        for (int c = lane; c < Bp; c += 64) s += (double)x[off + c] - (double)xold[off + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const double m = s / (double)B;
+        a += m * m;
+    }
+    __shared__ double sm[4];
+    if (lane == 0) sm[wave] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+
+__global__ void k_dxps_final(int T, int NBK, const double* __restrict__ part, double* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    double s = 0.0;
+    for (int k = 0; k < NBK; ++k) s += part[(size_t)t * NBK + k];
+    out[t] = sqrt(s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layout conversion between the reference's (B, Ts, N) tensors and the internal [T][N][Bp] layout,
+// through a 64x64 LDS tile so both sides are coalesced.  perm (optional) maps internal row i -> API
+// node.  pack zero-fills t >= Ts, b >= B.
+// ---------------------------------------------------------------------------------------------
+template <typename S>
+__global__ __launch_bounds__(256) void k_pack(int T, int Ts, int N, int B, int Bp, const int* __restrict__ perm,
+                                              const S* __restrict__ src, S* __restrict__ dst) {
+    __shared__ S tile[64][65];
+    const int i0 = blockIdx.x * 64, t = blockIdx.y, b0 = blockIdx.z * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = i0 + tx;
+    int node = -1;
+    if (i < N && t < Ts) node = perm ? perm[i] : i;
+    for (int bb = ty; bb < 64; bb += 4) {
+        const int b = b0 + bb;
+        S v = S(0);
+        if (node >= 0 && b < B) v = src[((size_t)b * Ts + t) * N + node];
+        tile[bb][tx] = v;
+    }
+    __syncthreads();
+    for (int ii = ty; ii < 64; ii += 4) {
+        if (i0 + ii < N) dst[((size_t)t * N + i0 + ii) * Bp + b0 + tx] = tile[tx][ii];
+    }
+}
+
+template <typename S>
+__global__ __launch_bounds__(256) void k_unpack(int T, int N, int B, int Bp, const int* __restrict__ perm,
+                                                const S* __restrict__ src, S* __restrict__ dst) {
+    __shared__ S tile[64][65];
+    const int i0 = blockIdx.x * 64, t = blockIdx.y, b0 = blockIdx.z * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int ii = ty; ii < 64; ii += 4) {
+        S v = S(0);
+        if (i0 + ii < N) v = src[((size_t)t * N + i0 + ii) * Bp + b0 + tx];
+        tile[ii][tx] = v;
+    }
+    __syncthreads();
+    const int i = i0 + tx;
+    if (i < N) {
+        const int node = perm ? perm[i] : i;
+        for (int bb = ty; bb < 64; bb += 4) {
+            const int b = b0 + bb;
+            if (b < B) dst[((size_t)b * T + t) * N + node] = tile[tx][bb];
+        }
+    }
+}
+
+template <typename S>
+__global__ void k_fill(S* __restrict__ p, size_t n, S v) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// initial_guess (ADMM.py:766-781): least-squares line per (node, sample) through t < t_in, in S
+// arithmetic with the reference's float32 time moments (tm, den passed from the host).
+template <typename S>
+__global__ __launch_bounds__(256) void k_initial_guess(int T, int t_in, int N, int Bp, S tm, S den,
+                                                       const S* __restrict__ y, S* __restrict__ x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    const int c = blockIdx.y * 64 + lane;
+    if (i >= N) return;
+    S sy = S(0), sty = S(0);
+    for (int t = 0; t < t_in; ++t) {
+        const S v = y[((size_t)t * N + i) * Bp + c];
+        x[((size_t)t * N + i) * Bp + c] = v;
+        sy += v;
+        sty += (S)t * v;
+    }
+    const S ym = sy / (S)t_in;
+    const S w = (sty / (S)t_in - tm * ym) / den;
+    const S b = ym - w * tm;
+    for (int t = t_in; t < T; ++t) x[((size_t)t * N + i) * Bp + c] = w * (S)t + b;
+}
+
+// initial_interpolation (ADMM.py:783-811).  F32MOM: time moments (n, t_mean, t2_mean) in float32 as the
+// reference gets them from a float32 mask, whatever the signal dtype.
+template <typename S, bool F32MOM>
+__global__ __launch_bounds__(256) void k_initial_interp(int T, int N, int Bp, int B, const S* __restrict__ y,
+                                                        const S* __restrict__ mask, S* __restrict__ x,
+                                                        int* __restrict__ nonfinite) {
+    typedef typename std::conditional<F32MOM, float, S>::type M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    const int c = blockIdx.y * 64 + lane;
+    if (i >= N) return;
+    if (c >= B) {
+        for (int t = 0; t < T; ++t) x[((size_t)t * N + i) * Bp + c] = S(0);
+        return;
+    }
+    M n = 0, ts = 0, t2s = 0;
+    S ys = 0, tys = 0;
+    for (int t = 0; t < T; ++t) {
+        const size_t o = ((size_t)t * N + i) * Bp + c;
+        const S m = mask[o], v = y[o];
+        n += (M)m;
+        ts += (M)t * (M)m;
+        t2s += (M)(t * t) * (M)m;
+        ys += v * m;
+        tys += (S)t * v * m;
+    }
+    const M tmean = ts / n, t2mean = t2s / n;
+    const S ymean = ys / (S)n, tymean = tys / (S)n;
+    const M den = t2mean - tmean * tmean;
+    const S w = (tymean - (S)tmean * ymean) / (S)den;
+    const S b = ymean - w * (S)tmean;
+    if (!(fabs((double)w) <= 1.79e308) || !(fabs((double)b) <= 1.79e308)) *nonfinite = 1;
+    for (int t = 0; t < T; ++t) {
+        const size_t o = ((size_t)t * N + i) * Bp + c;
+        x[o] = (w * (S)t + b) * (S(1) - mask[o]) + y[o];
+    }
+}

@@ -41,3 +41,15 @@ def has_gpu():
         return torch.cuda.is_available()
     except Exception:
         return False
+
+
+def _ensure_built():
+    """The product package cannot be imported without libmgadmm.so; build it in-tree if missing
+    (hipcc cross-compiles gfx950 without a GPU)."""
+    so = os.path.join(PKG, "mgadmm", "libmgadmm.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc")])
+
+
+_ensure_built()
