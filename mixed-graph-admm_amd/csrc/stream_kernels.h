@@ -677,6 +677,7 @@ __global__ void k_fill(S* __restrict__ p, size_t n, S v) {
 template <typename S>
 __global__ __launch_bounds__(256) void k_initial_guess(int T, int t_in, int N, int Bp, S tm, S den,
                                                        const S* __restrict__ y, S* __restrict__ x) {
+#pragma clang fp contract(off)  // the reference evaluates these scalars with separate roundings
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wave;
     const int c = blockIdx.y * 64 + lane;
@@ -700,6 +701,7 @@ template <typename S, bool F32MOM>
 __global__ __launch_bounds__(256) void k_initial_interp(int T, int N, int Bp, int B, const S* __restrict__ y,
                                                         const S* __restrict__ mask, S* __restrict__ x,
                                                         int* __restrict__ nonfinite) {
+#pragma clang fp contract(off)  // t2_mean - t_mean^2 cancels: keep the reference's separate roundings
     typedef typename std::conditional<F32MOM, float, S>::type M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wave;
@@ -722,7 +724,9 @@ __global__ __launch_bounds__(256) void k_initial_interp(int T, int N, int Bp, in
     }
     const M tmean = ts / n, t2mean = t2s / n;
     const S ymean = ys / (S)n, tymean = tys / (S)n;
-    const M den = t2mean - tmean * tmean;
+    M tm2 = tmean * tmean;
+    asm volatile("" : "+v"(tm2));   // keep the product rounded on its own: t2_mean - t_mean^2 cancels
+    const M den = t2mean - tm2;
     const S w = (tymean - (S)tmean * ymean) / (S)den;
     const S b = ymean - w * (S)tmean;
     if (!(fabs((double)w) <= 1.79e308) || !(fabs((double)b) <= 1.79e308)) *nonfinite = 1;

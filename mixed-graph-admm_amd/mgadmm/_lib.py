@@ -7,6 +7,10 @@ not been built (run ``python -c "import __graft_entry__ as g; g.build()"`` or
 import ctypes as C
 import os
 
+# torch first: it bundles its own libamdhip64.so.7; loading it before libmgadmm.so makes both share ONE
+# HIP runtime (device pointers, streams and events are exchanged between them).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgadmm.so")
 

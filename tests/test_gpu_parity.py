@@ -235,10 +235,15 @@ def check_solve(blk, key, G, abl, x, xtol, htol, it_slack):
     assert rel(x, G("x")) < xtol, key
     n = int(G("n_iters"))
     assert len(blk.p_res_list) == n
-    np.testing.assert_allclose(np.array(blk.p_res_list), G("p_res"), rtol=htol, atol=htol * 1e-3)
-    np.testing.assert_allclose(np.array(blk.d_res_list), G("d_res"), rtol=htol, atol=htol * 1e-3)
+    # residuals are norms of differences of O(|x|) numbers: absolute floor ~ eps * ||x|| (1e-8 ||x|| in f32)
+    floor = (1e-8 if htol >= 1e-4 else 1e-14) * float(np.linalg.norm(G("x")))
+    np.testing.assert_allclose(np.array(blk.p_res_list), G("p_res"), rtol=htol, atol=floor)
+    np.testing.assert_allclose(np.array(blk.d_res_list), G("d_res"), rtol=htol, atol=floor)
     np.testing.assert_allclose(blk.x_shift_list, G("x_shift"), rtol=htol)
-    np.testing.assert_allclose(torch.stack(blk.delta_x_per_step).numpy(), G("dxps"), rtol=htol, atol=htol * 1e-3)
+    # per-time-step norms of x - x_old: differences of O(100) float32 numbers, so the absolute error
+    # scales with the largest entry, not with each (possibly tiny) entry
+    np.testing.assert_allclose(torch.stack(blk.delta_x_per_step).numpy(), G("dxps"), rtol=htol,
+                               atol=htol * max(1e-3, float(G("dxps").max())))
     np.testing.assert_allclose(torch.stack(blk.GLR_list).numpy(), G("GLR"), rtol=htol)
     np.testing.assert_allclose(blk.recover_list, G("recover"), rtol=htol, atol=htol * 1e-2)
     if abl in ("None", "DGLR"):
