@@ -40,7 +40,7 @@ struct HostCsr {
 };
 
 struct DevCsr {
-    int n = 0, nnz = 0, max_row = 0;
+    int n = 0, nnz = 0, max_row = 0, avg_row_ceil = 0;
     int* rowptr = nullptr;
     int* col = nullptr;
     float* val = nullptr;

@@ -149,9 +149,13 @@ static int upload_csr(const HostCsr& h, DevCsr& d) {
     d.nnz = h.nnz();
     d.max_row = 0;
     for (int i = 0; i < h.n; ++i) d.max_row = std::max(d.max_row, h.rowptr[i + 1] - h.rowptr[i]);
+    d.avg_row_ceil = h.n ? (d.nnz + h.n - 1) / h.n : 0;
     MG_HIP(hipMalloc(&d.rowptr, sizeof(int) * (h.n + 1)));
-    MG_HIP(hipMalloc(&d.col, sizeof(int) * std::max(1, d.nnz)));
-    MG_HIP(hipMalloc(&d.val, sizeof(float) * std::max(1, d.nnz)));
+    // CSR_PAD (8) zeroed extra entries: the row kernels read a fixed window of entries per row
+    MG_HIP(hipMalloc(&d.col, sizeof(int) * (d.nnz + 8)));
+    MG_HIP(hipMalloc(&d.val, sizeof(float) * (d.nnz + 8)));
+    MG_HIP(hipMemset(d.col, 0, sizeof(int) * (d.nnz + 8)));
+    MG_HIP(hipMemset(d.val, 0, sizeof(float) * (d.nnz + 8)));
     MG_HIP(hipMemcpy(d.rowptr, h.rowptr.data(), sizeof(int) * (h.n + 1), hipMemcpyHostToDevice));
     if (d.nnz) {
         MG_HIP(hipMemcpy(d.col, h.col.data(), sizeof(int) * d.nnz, hipMemcpyHostToDevice));

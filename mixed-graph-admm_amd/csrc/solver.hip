@@ -54,7 +54,7 @@ struct Engine : EngineBase {
     double* h_row = nullptr;
     int* h_flag = nullptr;
     hipEvent_t ev_ring[LAG + 1] = {nullptr};
-    int want_blocks = 4096;
+    int want_blocks = 2048;
     int64_t ws_bytes = 0;
     // profiling
     bool prof_on = false;
@@ -90,18 +90,19 @@ struct Engine : EngineBase {
         q.VEC = vecw;
         q.Bp = (B + cw - 1) / cw * cw;
         q.CH = q.Bp / cw;
-        long per = 8L * T * q.CH;
-        int m = (int)((want_blocks + per - 1) / per);
-        int m_max = N / 64;
-        if (m_max < 1) m_max = 1;
-        if (m > m_max) m = m_max;
-        if (m < 1) m = 1;
-        q.NBX = m;
-        const int slots = 8 * m;
-        q.RB = (N + slots - 1) / slots;
-        q.NBLK = (N + q.RB - 1) / q.RB;
-        q.P = T * 8 * q.NBX;
-        q.grid = 8 * q.NBX * T * q.CH;
+        // persistent-sized grid: ~want_blocks workgroups in total, a multiple of 8 per column chunk
+        int g8 = want_blocks / (8 * q.CH);
+        if (g8 < 1) g8 = 1;
+        q.G8 = g8;
+        q.P = 8 * g8;
+        // rows per work item: 16 (4 per wave) unless the problem is too small to give every workgroup two items
+        long rows = (long)T * N;
+        int ri = 16;
+        while (ri > 4 && rows / ri < 2L * q.P) ri -= 4;
+        q.RI = ri;
+        q.NBLK = (N + ri - 1) / ri;
+        q.n_items = T * q.NBLK;
+        q.grid = q.P * q.CH;
         return q;
     }
 
@@ -239,24 +240,38 @@ struct Engine : EngineBase {
     }
 
     // ---------------------------------------------------------------- launch helpers
-    template <int VEC, class Epi>
+    template <int VEC, int GW, class Epi>
     int rows_v(const Geom& q, const OpDesc& op, const S* in, const Epi& epi, const int* live, int tag, double bytes) {
         const bool timed = prof_open(tag, bytes);
-        hipLaunchKernelGGL((k_rows<S, VEC, Epi>), dim3(q.grid), dim3(256), 0, st, q, op, op.rowptr, op.col, op.val, op.band_w, in,
-                           epi, partials, live);
+        hipLaunchKernelGGL((k_rows<S, VEC, Epi, GW>), dim3(q.grid), dim3(256), 0, st, q, op, op.rowptr, op.col, op.val,
+                           op.band_w, in, epi, partials, live);
         if (timed) prof_close();
         MG_HIP(hipGetLastError());
         return MGADMM_OK;
     }
 
+    // gather window of the row kernel: 4 in-flight neighbour rows for the k=4 spatial Laplacian, 6 otherwise
+    int gather_width(const OpDesc& op) const {
+        if (op.kind != OPK_SPATIAL) return 4;
+        int mr = op.rowptr == g->Wu.rowptr ? g->Wu.max_row : (op.rowptr == g->Wd.rowptr ? g->Wd.max_row : g->WdT.avg_row_ceil);
+        return mr <= 4 ? 4 : 6;
+    }
+
     template <template <typename, int> class E, class... A>
     int rows(const Geom& q, const OpDesc& op, const S* in, const int* live, int tag, int passes, A... a) {
         const double bytes = pass_bytes(q, passes) + csr_bytes(op);
+        const bool wide = gather_width(op) > 4;
         switch (q.VEC) {
-            case 1: return rows_v<1>(q, op, in, E<S, 1>{a...}, live, tag, bytes);
-            case 2: return rows_v<2>(q, op, in, E<S, 2>{a...}, live, tag, bytes);
+            case 1:
+                return wide ? rows_v<1, 6>(q, op, in, E<S, 1>{a...}, live, tag, bytes)
+                            : rows_v<1, 4>(q, op, in, E<S, 1>{a...}, live, tag, bytes);
+            case 2:
+                return wide ? rows_v<2, 6>(q, op, in, E<S, 2>{a...}, live, tag, bytes)
+                            : rows_v<2, 4>(q, op, in, E<S, 2>{a...}, live, tag, bytes);
             case 4:
-                if constexpr (sizeof(S) == 4) return rows_v<4>(q, op, in, E<S, 4>{a...}, live, tag, bytes);
+                if constexpr (sizeof(S) == 4)
+                    return wide ? rows_v<4, 6>(q, op, in, E<S, 4>{a...}, live, tag, bytes)
+                                : rows_v<4, 4>(q, op, in, E<S, 4>{a...}, live, tag, bytes);
         }
         mg_set_error("rows: unsupported VEC %d", q.VEC);
         return MGADMM_ERR_UNSUPPORTED;

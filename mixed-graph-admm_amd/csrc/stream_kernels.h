@@ -32,44 +32,29 @@ __device__ __forceinline__ void stv(S* p, const Vec<S, V>& x) {
 struct Geom {
     int T, N, B, Bp;
     int VEC, CH;         // columns per lane; column chunks of 64*VEC
-    int RB, NBLK, NBX;   // rows per workgroup, node-blocks per time slice, node-block slots per XCD
-    int P;               // partial-sum rows per column = T * 8 * NBX
-    int grid;            // 8 * NBX * T * CH workgroups
+    int RI, NBLK;        // rows per work item; items per time slice = ceil(N / RI)
+    int n_items;         // T * NBLK work items per column chunk, enumerated t-major
+    int G8;              // workgroups per (XCD, column chunk)
+    int P;               // partial-sum rows per column = 8 * G8 (one per workgroup of a chunk)
+    int grid;            // 8 * G8 * CH workgroups
 };
 
+constexpr int CSR_PAD = 8;     // col/val arrays carry this many extra entries (reads past a row end are safe)
+
 // ---------------------------------------------------------------------------------------------
-// l = op(in) at row (t,i) for this lane's VEC columns.
-//   SPATIAL: l = selfc(t) * in[t][i] - sum_e val[e] * in[t+shift][col[e]]      (Lu, Ldr, Ldr^T)
-//   BAND   : l = selfc(t) * in[t][i] - sum_s w[.][s] * in[t -/+ (1+s)][i]      (line graph)
-//   NONE   : l = in[t][i]
-// Reference: ADMM.py:138-223.
+// Band (line-graph) operators and the no-gather case:
+//   BAND : l = selfc(t) * in[t][i] - sum_s w[.][s] * in[t -/+ (1+s)][i]      (ADMM.py:153-164, 181-194)
+//   NONE : l = in[t][i]
 // ---------------------------------------------------------------------------------------------
 template <typename S, int VEC>
-__device__ __forceinline__ Vec<S, VEC> op_apply(const Geom& g, const OpDesc& op, const int* __restrict__ rowptr,
-                                                const int* __restrict__ colidx, const float* __restrict__ val,
-                                                const float* __restrict__ band_w, const S* __restrict__ in, int t,
-                                                int i, int col0, const Vec<S, VEC>& self) {
+__device__ __forceinline__ Vec<S, VEC> op_apply_band(const Geom& g, const OpDesc& op, const float* __restrict__ band_w,
+                                                     const S* __restrict__ in, int t, int i, int col0,
+                                                     const Vec<S, VEC>& self) {
     Vec<S, VEC> sum;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) sum.v[v] = S(0);
     S selfc = S(1);
-    if (op.kind == OPK_SPATIAL) {
-        const int ts = t + op.shift;
-        if (op.self_mode == SELF_LDR) selfc = (t >= 1) ? S(1) : S(0);
-        else if (op.self_mode == SELF_LDRT) selfc = (t > 0 || op.q1) ? S(1) : S(0);
-        if (ts >= 0 && ts < g.T) {
-            const S* base = in + (size_t)ts * g.N * g.Bp + col0;
-            const int e0 = rowptr[i], e1 = rowptr[i + 1];
-#pragma unroll 2
-            for (int e = e0; e < e1; ++e) {
-                const int c = colidx[e];
-                const S w = (S)val[e];
-                const Vec<S, VEC> nv = ldv<S, VEC>(base + (size_t)c * g.Bp);
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) sum.v[v] += w * nv.v[v];
-            }
-        }
-    } else if (op.kind == OPK_BAND) {
+    if (op.kind == OPK_BAND) {
         if (op.band_dir < 0) {
             selfc = (t >= 1) ? S(1) : S(0);
             for (int s = 0; s < op.skip; ++s) {
@@ -98,14 +83,50 @@ __device__ __forceinline__ Vec<S, VEC> op_apply(const Geom& g, const OpDesc& op,
     return l;
 }
 
+// wave-uniform description of one CSR row: bounds + the first GW (column, weight) pairs;
+// slots past the row end are redirected to the row's own node with weight 0
+template <int GW>
+struct RowMeta {
+    int e0, e1;
+    int c[GW];
+    float w[GW];
+};
+
+__device__ __forceinline__ void row_bounds(const int* __restrict__ rowptr, int i, int& e0, int& e1) {
+    e0 = rowptr[i];
+    e1 = rowptr[i + 1];
+}
+
+template <int GW>
+__device__ __forceinline__ void row_entries(const int* __restrict__ colidx, const float* __restrict__ val, int e0, int e1,
+                                            int iself, RowMeta<GW>& m) {
+    m.e0 = e0;
+    m.e1 = e1;
+#pragma unroll
+    for (int u = 0; u < GW; ++u) {
+        const int cc = colidx[e0 + u];     // unconditional: arrays are padded by CSR_PAD entries
+        const float ww = val[e0 + u];
+        const bool ok = e0 + u < e1;
+        m.c[u] = ok ? cc : iself;
+        m.w[u] = ok ? ww : 0.0f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
-// Row kernel: every wave walks node rows of one (column chunk, time slice, node block); the epilogue
-// functor fuses the element-wise work of the caller (LHS combination, CG dot, prox, dual update, ...).
+// Row kernel.  Work item = RI consecutive node rows of one time slice; items are enumerated t-major
+// (all node blocks of slice 0, then slice 1, ...).  The grid is persistent-sized (8*G8 workgroups per
+// column chunk): in round k the whole chunk group works on items [k*P, (k+1)*P) and XCD x on the
+// contiguous eighth [k*P + x*G8, +G8) of them.  So (a) every XCD sweeps contiguous node ranges (the
+// neighbour rows of a spatial gather are rows its own L2 has just fetched), and (b) the whole device
+// moves through time slices together, so the rows a time-shifted operator (Ldr / Ldr^T) gathers from
+// slice t -/+ 1 were streamed a few tens of MB ago and are still in the 256 MiB Infinity Cache.
+// Each wave owns rows (wave, wave+4, ...) of an item over 64*VEC batch columns; CSR metadata of the
+// next row is prefetched through the scalar cache while the gathers of the current row are in flight.
 // partials: [NRED][P][Bp] per-workgroup per-column partial sums (summed by k_reduce in fixed order).
 // live: optional device flag; a zero value makes the launch a no-op (speculatively enqueued CG
 // iterations after every sample has converged).
 // ---------------------------------------------------------------------------------------------
-template <typename S, int VEC, class Epi>
+template <typename S, int VEC, class Epi, int GW>
 __global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __restrict__ rowptr,
                                               const int* __restrict__ colidx, const float* __restrict__ val,
                                               const float* __restrict__ band_w, const S* __restrict__ in, Epi epi_in,
@@ -113,48 +134,105 @@ __global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __re
     if (live != nullptr && *live == 0) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    int j = blockIdx.x >> 3;
     const int xcd = blockIdx.x & 7;
-    const int nbl = j % g.NBX;
-    j /= g.NBX;
-    const int t = j % g.T;
-    const int chunk = j / g.T;
-    const int nb = xcd * g.NBX + nbl;
+    const int q = blockIdx.x >> 3;
+    const int chunk = q % g.CH;
+    const int r = q / g.CH;
     const int col0 = (chunk * 64 + lane) * VEC;
+    const int slot = xcd * g.G8 + r;       // this workgroup's position inside a round / partial row
 
     Epi epi = epi_in;
     epi.begin(col0);
     constexpr int NR = Epi::NRED > 0 ? Epi::NRED : 1;
     S acc[NR][VEC];
 #pragma unroll
-    for (int r = 0; r < NR; ++r)
+    for (int rr = 0; rr < NR; ++rr)
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[r][v] = S(0);
+        for (int v = 0; v < VEC; ++v) acc[rr][v] = S(0);
 
-    const int n0 = nb * g.RB;
-    const int n1 = (nb < g.NBLK) ? min(g.N, n0 + g.RB) : n0;
-    for (int i = n0 + wave; i < n1; i += 4) {
-        const size_t off = ((size_t)t * g.N + i) * g.Bp + col0;
-        const Vec<S, VEC> self = ldv<S, VEC>(in + off);
-        const Vec<S, VEC> l = op_apply<S, VEC>(g, op, rowptr, colidx, val, band_w, in, t, i, col0, self);
-        epi.row(t, off, self, l, acc);
+    const bool spatial = op.kind == OPK_SPATIAL;
+    for (int item = slot; item < g.n_items; item += g.P) {
+        const int t = item / g.NBLK;
+        const int nb = item - t * g.NBLK;
+        const int n0 = nb * g.RI;
+        const int n1 = min(g.N, n0 + g.RI);
+        int i = n0 + wave;
+        if (i >= n1) continue;
+        if (spatial) {
+            const int ts = t + op.shift;
+            const bool tvalid = ts >= 0 && ts < g.T;
+            S selfc = S(1);
+            if (op.self_mode == SELF_LDR) selfc = (t >= 1) ? S(1) : S(0);
+            else if (op.self_mode == SELF_LDRT) selfc = (t > 0 || op.q1) ? S(1) : S(0);
+            const S* gbase = in + (size_t)(tvalid ? ts : t) * g.N * g.Bp + col0;   // slice the gathers read
+            const S* obase = in + (size_t)t * g.N * g.Bp + col0;                  // slice of the rows we own
+            RowMeta<GW> cur, nxt;
+            int be0, be1, ne0, ne1;
+            row_bounds(rowptr, i, be0, be1);
+            if (!tvalid) be1 = be0;
+            row_entries<GW>(colidx, val, be0, be1, i, cur);
+            row_bounds(rowptr, min(i + 4, g.N - 1), ne0, ne1);
+            if (!tvalid) ne1 = ne0;
+            for (; i < n1; i += 4) {
+                const size_t roff = (size_t)i * g.Bp;
+                Vec<S, VEC> sum;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) sum.v[v] = S(0);
+                if (cur.e1 - cur.e0 > GW) {          // entries past the fixed gather window (rare rows)
+                    for (int e = cur.e0 + GW; e < cur.e1; ++e) {
+                        const Vec<S, VEC> x = ldv<S, VEC>(gbase + (size_t)colidx[e] * g.Bp);
+                        const S w = (S)val[e];
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) sum.v[v] += w * x.v[v];
+                    }
+                }
+                // own row + GW neighbour rows in flight together; pad slots re-read the own node (weight 0)
+                const Vec<S, VEC> self = ldv<S, VEC>(obase + roff);
+                Vec<S, VEC> nv[GW];
+#pragma unroll
+                for (int u = 0; u < GW; ++u) nv[u] = ldv<S, VEC>(gbase + (size_t)cur.c[u] * g.Bp);
+                __builtin_amdgcn_sched_barrier(0);   // keep the loads issued up here
+                // scalar prefetch for the rows this wave handles next (one and two steps ahead)
+                row_entries<GW>(colidx, val, ne0, ne1, min(i + 4, g.N - 1), nxt);
+                int fe0, fe1;
+                row_bounds(rowptr, min(i + 8, g.N - 1), fe0, fe1);
+                if (!tvalid) fe1 = fe0;
+#pragma unroll
+                for (int u = 0; u < GW; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) sum.v[v] += (S)cur.w[u] * nv[u].v[v];
+                Vec<S, VEC> l;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) l.v[v] = selfc * self.v[v] - sum.v[v];
+                epi.row(t, (size_t)t * g.N * g.Bp + roff + col0, self, l, acc);
+                cur = nxt;
+                ne0 = fe0;
+                ne1 = fe1;
+            }
+        } else {
+            for (; i < n1; i += 4) {
+                const size_t off = ((size_t)t * g.N + i) * g.Bp + col0;
+                const Vec<S, VEC> self = ldv<S, VEC>(in + off);
+                const Vec<S, VEC> l = op_apply_band<S, VEC>(g, op, band_w, in, t, i, col0, self);
+                epi.row(t, off, self, l, acc);
+            }
+        }
     }
 
     if (Epi::NRED > 0) {
         __shared__ S sm[3][VEC][64];
-        const int p = (t * 8 + xcd) * g.NBX + nbl;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
+        for (int rr = 0; rr < NR; ++rr) {
             if (wave > 0) {
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) sm[wave - 1][v][lane] = acc[r][v];
+                for (int v = 0; v < VEC; ++v) sm[wave - 1][v][lane] = acc[rr][v];
             }
             __syncthreads();
             if (wave == 0) {
                 Vec<S, VEC> o;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) o.v[v] = ((acc[r][v] + sm[0][v][lane]) + sm[1][v][lane]) + sm[2][v][lane];
-                stv<S, VEC>(partials + ((size_t)r * g.P + p) * g.Bp + col0, o);
+                for (int v = 0; v < VEC; ++v) o.v[v] = ((acc[rr][v] + sm[0][v][lane]) + sm[1][v][lane]) + sm[2][v][lane];
+                stv<S, VEC>(partials + ((size_t)rr * g.P + slot) * g.Bp + col0, o);
             }
             __syncthreads();
         }
