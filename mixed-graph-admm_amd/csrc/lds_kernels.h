@@ -1,0 +1,555 @@
+// LDS-resident fused ADMM iteration for small graphs (PEMS-size: T*N*8 B + CSR fits the 160 KiB LDS).
+//
+// One workgroup = one sample.  One launch = one full ADMM iteration of reference ADMM.py:546-646:
+// RHS_x, the three CG solves (x, zu, zd) with all their iterations, the dual updates, the phi prox and
+// every residual / regulariser of the history.  Inside a CG solve nothing touches HBM:
+//   * thread (g, i) owns node i at TPG consecutive time steps t0 = g*TPG ...; x, r, p, Ap of those
+//     elements live in registers for the whole solve;
+//   * the CG direction p (and q = Ldr p) live in LDS so that neighbours can be gathered;
+//   * the three CSR matrices (W_u, W_d, W_d^T as packed {col, weight} pairs) live in LDS too; a thread
+//     reads each entry of ITS node's row once per operator application and applies it to its TPG time steps;
+//   * p.Ap and r.r are reduced with wave shuffles + a 16-entry LDS exchange in fixed order (repeatable);
+//     alpha, beta and the convergence test are computed redundantly by every thread (workgroup-uniform).
+// State (x, zu, zd, phi, gamma*) is kept in HBM in the reference's own sample-major (B, T*N) layout, so the
+// ABI tensors need no layout conversion on this path; per ADMM iteration a sample moves ~35 vectors of
+// T*N*4 B through HBM instead of ~650.
+#pragma once
+#include "common.h"
+
+struct LdsArgs {
+    int T, N, TN, t_in, G, B, Bp;
+    int nthreads;          // N * G active threads
+    int has_phi, has_zd, first;
+    int lhsx_kind;         // 1: LHS_x contains cLdr, 0: diagonal ('DGTV'/'UT')
+    int band, skip, q1;
+    int max_cg;
+    int record;            // alpha/beta history
+    float rho, rho_u, rho_d, mu_u, mu_d1, mu_d2;
+    float cx1, cx2;        // LHS_x = HtH + cx1*I + cx2*cLdr
+    double cg_tol;
+    // CSR image (global): ints laid out as [rp_u N+1][rp_d N+1][rp_t N+1][ent_u 2*nnz_u][ent_d ..][ent_t ..]
+    const int* csr;
+    int csr_ints, off_rp_u, off_rp_d, off_rp_t, off_en_u, off_en_d, off_en_t;
+    const float* band_w;   // [T*skip] (band mode)
+    // state, sample-major (B, TN)
+    const float* x_old;
+    float* x_new;
+    float *zu, *zd, *phi, *gam, *gu, *gd;
+    const float* y;        // (B, t_in, N) prediction / (B, T, N) mask mode
+    const float* mask;     // (B, T, N) or nullptr
+    // outputs
+    double* ps;            // [NMETRIC][Bp] per-sample metric sums
+    int* cg_iters;         // [3][Bp]
+    float* alpha_hist;     // [3][max_cg][Bp] or nullptr
+    float* beta_hist;
+    int* nonfinite;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Fixed-order workgroup sum; `red` has 2 x 16 doubles used alternately (one barrier per call).
+struct BlockRed {
+    double* red;
+    int par;
+    int lane, wave, nwaves;
+    __device__ __forceinline__ double sum(double v) {
+        v = wave_sum(v);
+        double* buf = red + par * 16;
+        if (lane == 0) buf[wave] = v;
+        __syncthreads();
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += buf[w];
+        par ^= 1;
+        return s;
+    }
+};
+
+template <int TPG>
+struct LdsCtx {
+    int T, N, t0, i;
+    bool active;
+    float* P;
+    float* Q;
+    float* AP;
+    const int2* en_u; const int2* en_d; const int2* en_t;
+    int u0, u1, d0, d1, t0e, t1e;   // this node's CSR row bounds
+    int band, skip, q1;
+    const float* band_w;
+
+    __device__ __forceinline__ int el(int k) const { return (t0 + k) * N + i; }
+
+    // acc[k] = sum_e w_e * SRC[(t0+k+shift)*N + col_e]
+    __device__ __forceinline__ void gather(const float* SRC, const int2* EN, int e0, int e1, int shift, float (&acc)[TPG]) const {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const int2 en = EN[e];
+            const float w = __int_as_float(en.y);
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) {
+                const int tt = t0 + k + shift;
+                if (tt >= 0 && tt < T) acc[k] += w * SRC[tt * N + en.x];
+            }
+        }
+    }
+    // l = Lu(src): src values of the own elements in `self`, neighbours from SRC (LDS)     ADMM.py:138-148
+    __device__ __forceinline__ void op_lu(const float* SRC, float (&l)[TPG]) const {
+        float acc[TPG];
+        gather(SRC, en_u, u0, u1, 0, acc);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) l[k] = SRC[el(k)] - acc[k];
+    }
+    // l = Ldr(src)      ADMM.py:150-177
+    __device__ __forceinline__ void op_ldr(const float* SRC, float (&l)[TPG]) const {
+        float acc[TPG];
+        if (!band) {
+            gather(SRC, en_d, d0, d1, -1, acc);
+        } else {
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) {
+                acc[k] = 0.f;
+                const int t = t0 + k;
+                for (int s = 0; s < skip; ++s) {
+                    const int tt = t - 1 - s;
+                    if (tt < 0) break;
+                    acc[k] += band_w[t * skip + s] * SRC[tt * N + i];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) l[k] = ((t0 + k >= 1) ? SRC[el(k)] : 0.f) - acc[k];
+    }
+    // l = Ldr_T(src)    ADMM.py:179-223 (q1: identity kept on the t=0 block)
+    __device__ __forceinline__ void op_ldrt(const float* SRC, float (&l)[TPG]) const {
+        float acc[TPG];
+        if (!band) {
+            gather(SRC, en_t, t0e, t1e, +1, acc);
+        } else {
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) {
+                acc[k] = 0.f;
+                const int t = t0 + k;
+                for (int s = 0; s < skip; ++s) {
+                    const int tt = t + 1 + s;
+                    if (tt >= T) break;
+                    acc[k] += band_w[tt * skip + s] * SRC[tt * N + i];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) l[k] = ((t0 + k > 0 || q1) ? SRC[el(k)] : 0.f) - acc[k];
+    }
+    __device__ __forceinline__ void put(float* DST, const float (&v)[TPG]) const {
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) DST[el(k)] = v[k];
+        }
+    }
+};
+
+// AP = A v for the vector v held in ctx.P (LDS):
+//   KIND 1: d*v + c1*v + c2*Ldr_T(Ldr v) ; KIND 2: c1*v + c2*Lu v ; KIND 0: d*v + c1*v
+// d = dg[el] when dg != nullptr (mask values, global memory), else [hth && t < t_in].
+// Own elements of the result go to ctx.AP (LDS); returns sum_k v_k * (A v)_k of the own elements.
+// Uses ctx.Q as scratch; contains a barrier for KIND 1.  Callers separate successive calls by barriers.
+template <int TPG, int KIND>
+__device__ __forceinline__ double lds_apply(const LdsCtx<TPG>& c, const float* dg, int hth, int t_in, float c1, float c2) {
+    float l[TPG];
+#pragma unroll
+    for (int k = 0; k < TPG; ++k) l[k] = 0.f;
+    if (KIND == 1) {
+        if (c.active) {
+            float q[TPG];
+            c.op_ldr(c.P, q);
+            c.put(c.Q, q);
+        }
+        __syncthreads();
+        if (c.active) c.op_ldrt(c.Q, l);
+    } else if (KIND == 2) {
+        if (c.active) c.op_lu(c.P, l);
+    }
+    double part = 0.0;
+    if (c.active) {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            const int e = c.el(k);
+            const float v = c.P[e];
+            float d = 0.f;
+            if (KIND != 2) d = dg ? dg[e] : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
+            const float av = d * v + c1 * v + c2 * l[k];
+            c.AP[e] = av;
+            part += (double)v * (double)av;
+        }
+    }
+    return part;
+}
+
+// CG_solver (ADMM.py:329-368) for one sample.  x, r of the own elements live in registers, the direction
+// p in LDS (ctx.P), A p in LDS (ctx.AP).  x holds x0 on entry and the solution on exit.  dmask: diagonal
+// of the initial residual when a mask is given (global memory); the iterations always use [t<t_in]
+// (quirk Q2).  Returns the iteration count (k+1) or -1.  Entry requirement: no thread still reads P/Q.
+template <int TPG, int KIND>
+__device__ __forceinline__ int lds_cg(const LdsCtx<TPG>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
+                      int hth, int t_in, float c1, float c2, int max_cg, double tol, float* ah, float* bh, int Bp,
+                      int* nonfinite) {
+    float r[TPG];
+#pragma unroll
+    for (int k = 0; k < TPG; ++k) r[k] = 0.f;
+    c.put(c.P, x);
+    __syncthreads();
+    (void)lds_apply<TPG, KIND>(c, dmask, hth, t_in, c1, c2);
+    double part = 0.0;
+    if (c.active) {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            r[k] = rhs[k] - c.AP[c.el(k)];
+            part += (double)r[k] * (double)r[k];
+        }
+    }
+    float rr = (float)br.sum(part);      // barrier: every read of P (= x0) is done
+    c.put(c.P, r);                       // p = r
+    int iters = -1;
+    for (int it = 0; it < max_cg; ++it) {
+        __syncthreads();                 // p complete in LDS
+        part = lds_apply<TPG, KIND>(c, nullptr, hth, t_in, c1, c2);
+        const float pAp = (float)br.sum(part);   // barrier: every gather from P/Q of this iteration is done
+        const float alpha = rr / pAp;
+        part = 0.0;
+        if (c.active) {
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) {
+                const int e = c.el(k);
+                x[k] = x[k] + alpha * c.P[e];
+                r[k] = r[k] - alpha * c.AP[e];
+                part += (double)r[k] * (double)r[k];
+            }
+        }
+        const float rrn = (float)br.sum(part);
+        const float beta = rrn / rr;
+        rr = rrn;
+        if (ah != nullptr && threadIdx.x == 0) {
+            ah[(size_t)it * Bp] = alpha;
+            bh[(size_t)it * Bp] = beta;
+        }
+        if (!(fabsf(rrn) <= 3.0e38f)) {       // NaN / Inf: report and stop this sample
+            if (threadIdx.x == 0) *nonfinite = 1;
+            break;
+        }
+        if ((double)sqrtf(rrn) < tol) {
+            iters = it + 1;
+            break;
+        }
+        if (c.active) {
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) {
+                const int e = c.el(k);
+                c.P[e] = r[k] + beta * c.P[e];
+            }
+        }
+    }
+    return iters;
+}
+
+template <int TPG>
+__global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    float* P = reinterpret_cast<float*>(lds_raw);
+    float* Q = P + a.TN;
+    float* AP = Q + a.TN;
+    double* red = reinterpret_cast<double*>(AP + a.TN + (a.TN & 1));  // 8-byte aligned
+    int* csr = reinterpret_cast<int*>(red + 32);
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    for (int k = tid; k < a.csr_ints; k += blockDim.x) csr[k] = a.csr[k];
+
+    LdsCtx<TPG> c;
+    c.T = a.T; c.N = a.N;
+    c.active = tid < a.nthreads;
+    const int g = c.active ? tid / a.N : 0;
+    c.i = c.active ? tid - g * a.N : 0;
+    c.t0 = g * TPG;
+    c.P = P; c.Q = Q; c.AP = AP;
+    c.band = a.band; c.skip = a.skip; c.q1 = a.q1; c.band_w = a.band_w;
+    c.en_u = reinterpret_cast<const int2*>(csr + a.off_en_u);
+    c.en_d = reinterpret_cast<const int2*>(csr + a.off_en_d);
+    c.en_t = reinterpret_cast<const int2*>(csr + a.off_en_t);
+    __syncthreads();
+    c.u0 = csr[a.off_rp_u + c.i]; c.u1 = csr[a.off_rp_u + c.i + 1];
+    c.d0 = c.d1 = c.t0e = c.t1e = 0;
+    if (!a.band) {
+        c.d0 = csr[a.off_rp_d + c.i]; c.d1 = csr[a.off_rp_d + c.i + 1];
+        c.t0e = csr[a.off_rp_t + c.i]; c.t1e = csr[a.off_rp_t + c.i + 1];
+    }
+    BlockRed br;
+    br.red = red; br.par = 0; br.lane = tid & 63; br.wave = tid >> 6; br.nwaves = (blockDim.x + 63) >> 6;
+
+    const size_t sb = (size_t)b * a.TN;
+    const float* xo = a.x_old + sb;
+    float* xn = a.x_new + sb;
+    float *zu = a.zu + sb, *zd = a.zd + sb, *phi = a.phi + sb, *gam = a.gam + sb, *gu = a.gu + sb, *gd = a.gd + sb;
+    const float* mk = a.mask ? a.mask + sb : nullptr;
+    const int ty = a.mask ? a.T : a.t_in;
+    const float* yb = a.y + (size_t)b * ty * a.N;
+
+    float x[TPG];
+#pragma unroll
+    for (int k = 0; k < TPG; ++k) x[k] = c.active ? xo[c.el(k)] : 0.f;
+
+    // ---- first iteration only: phi = Ldr x0 (ADMM.py:541); the dual variables were filled by k_init_lds
+    if (a.has_phi && a.first) {
+        float ph[TPG];
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) ph[k] = 0.f;
+        c.put(P, x);
+        __syncthreads();
+        if (c.active) c.op_ldr(P, ph);
+        c.put(phi, ph);
+        __syncthreads();
+    }
+
+    // ---- RHS_x (ADMM.py:556-564)
+    float rhs[TPG];
+    {
+        float l[TPG];
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) l[k] = 0.f;
+        if (a.has_phi) {
+            float v[TPG];
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) v[k] = c.active ? gam[c.el(k)] + a.rho * phi[c.el(k)] : 0.f;
+            c.put(P, v);
+            __syncthreads();
+            if (c.active) c.op_ldrt(P, l);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            rhs[k] = 0.f;
+            if (c.active) {
+                const int e = c.el(k);
+                const int t = c.t0 + k;
+                const float yv = (t < ty) ? yb[t * a.N + c.i] : 0.f;
+                float o;
+                if (a.has_zd) o = (a.rho_u * zu[e] + a.rho_d * zd[e]) / 2.f - (gu[e] + gd[e]) / 2.f + yv;
+                else o = a.rho_u * zu[e] / 2.f - gu[e] / 2.f + yv;
+                rhs[k] = a.has_phi ? l[k] / 2.f + o : o;
+            }
+        }
+    }
+    float* ah = a.record ? a.alpha_hist + b : nullptr;
+    float* bh = a.record ? a.beta_hist + b : nullptr;
+    const size_t hstride = (size_t)a.max_cg * a.Bp;
+
+    // ---- x solve (ADMM.py:571)
+    int itx;
+    if (a.lhsx_kind == 1) itx = lds_cg<TPG, 1>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, a.cx2, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
+    else itx = lds_cg<TPG, 0>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, 0.f, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
+    c.put(xn, x);
+
+    double m_xshift = 0, m_prizu = 0, m_dualzu = 0, m_prizd = 0, m_dualzd = 0, m_rec = 0;
+    if (c.active) {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            const int t = c.t0 + k;
+            const double dx = (double)x[k] - (double)xo[c.el(k)];
+            m_xshift += dx * dx;
+            if (mk) {
+                const double e = (double)(x[k] * mk[c.el(k)] - yb[t * a.N + c.i]);
+                m_rec += e * e;
+            } else if (t < a.t_in) {
+                const double e = (double)(x[k] - yb[t * a.N + c.i]);
+                m_rec += e * e;
+            }
+        }
+    }
+
+    // ---- zu solve + gamma_u update (ADMM.py:579-580, 595)
+    int itzu;
+    {
+        float z[TPG];
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            z[k] = 0.f;
+            if (c.active) {
+                z[k] = zu[c.el(k)];
+                rhs[k] = gu[c.el(k)] / 2.f + a.rho_u / 2.f * xn[c.el(k)];
+            }
+        }
+        itzu = lds_cg<TPG, 2>(c, br, z, rhs, nullptr, 0, 0, a.rho_u / 2.f, a.mu_u, a.max_cg, a.cg_tol, ah ? ah + hstride : nullptr,
+                              bh ? bh + hstride : nullptr, a.Bp, a.nonfinite);
+        if (c.active) {
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) {
+                const int e = c.el(k);
+                const float pz = xn[e] - z[k], dz = z[k] - zu[e];
+                m_prizu += (double)pz * pz;
+                m_dualzu += (double)dz * dz;
+                zu[e] = z[k];
+                gu[e] = gu[e] + a.rho_u * pz;
+            }
+        }
+    }
+    // ---- zd solve + gamma_d update (ADMM.py:586-588, 597)
+    int itzd = 0;
+    if (a.has_zd) {
+        float z[TPG];
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            z[k] = 0.f;
+            if (c.active) {
+                z[k] = zd[c.el(k)];
+                rhs[k] = gd[c.el(k)] / 2.f + a.rho_d / 2.f * xn[c.el(k)];
+            }
+        }
+        itzd = lds_cg<TPG, 1>(c, br, z, rhs, nullptr, 0, 0, a.rho_d / 2.f, a.mu_d2, a.max_cg, a.cg_tol,
+                              ah ? ah + 2 * hstride : nullptr, bh ? bh + 2 * hstride : nullptr, a.Bp, a.nonfinite);
+        if (c.active) {
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) {
+                const int e = c.el(k);
+                const float pz = xn[e] - z[k], dz = z[k] - zd[e];
+                m_prizd += (double)pz * pz;
+                m_dualzd += (double)dz * dz;
+                zd[e] = z[k];
+                gd[e] = gd[e] + a.rho_d * pz;
+            }
+        }
+    }
+
+    // ---- phi prox, gamma update, Ldr/Lu based diagnostics (ADMM.py:600-606, 619, 627-637)
+    double m_priphi = 0, m_dualphi = 0, m_dgtv = 0, m_dglr = 0, m_glr = 0;
+    __syncthreads();          // every LDS read of the last CG is done
+    if (c.active) {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) P[c.el(k)] = xn[c.el(k)];
+    }
+    __syncthreads();
+    if (c.active) {
+        float l[TPG];
+        c.op_ldr(P, l);
+        const float thr = a.mu_d1 / a.rho;
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            m_dgtv += fabs((double)l[k]);
+            m_dglr += (double)l[k] * l[k];
+            if (a.has_phi) {
+                const int e = c.el(k);
+                const float gv = gam[e];
+                const float s = l[k] - gv / a.rho;
+                const float u = fabsf(s) - thr;
+                const float pn = (u > 0.f) ? (s > 0.f ? u : -u) : 0.f;
+                const float dd = pn - l[k], dp = pn - phi[e];
+                m_priphi += (double)dd * dd;
+                m_dualphi += (double)dp * dp;
+                phi[e] = pn;
+                gam[e] = gv + a.rho * dd;
+            }
+        }
+        c.op_lu(P, l);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) m_glr += (double)P[c.el(k)] * (double)l[k];
+    }
+
+    // ---- per-sample metric sums (whole-batch values are formed by k_batch_metrics)
+    double vals[MGADMM_NMETRIC];
+    vals[MGADMM_M_XSHIFT] = m_xshift; vals[MGADMM_M_PRI_ZU] = m_prizu; vals[MGADMM_M_DUAL_ZU] = m_dualzu;
+    vals[MGADMM_M_PRI_PHI] = m_priphi; vals[MGADMM_M_DUAL_PHI] = m_dualphi; vals[MGADMM_M_PRI_ZD] = m_prizd;
+    vals[MGADMM_M_DUAL_ZD] = m_dualzd; vals[MGADMM_M_GLR] = m_glr; vals[MGADMM_M_DGTV] = m_dgtv;
+    vals[MGADMM_M_DGLR] = m_dglr; vals[MGADMM_M_RECOVER] = m_rec;
+#pragma unroll
+    for (int m = 0; m < MGADMM_NMETRIC; ++m) {
+        const double s = br.sum(vals[m]);
+        bool keep = true;
+        if ((m == MGADMM_M_PRI_PHI || m == MGADMM_M_DUAL_PHI || m == MGADMM_M_DGTV) && !a.has_phi) keep = false;
+        if ((m == MGADMM_M_PRI_ZD || m == MGADMM_M_DUAL_ZD || m == MGADMM_M_DGLR) && !a.has_zd) keep = false;
+        if (tid == 0) a.ps[(size_t)m * a.Bp + b] = keep ? s : 0.0;
+    }
+    if (tid == 0) {
+        a.cg_iters[b] = itx;
+        a.cg_iters[a.Bp + b] = itzu;
+        a.cg_iters[2 * a.Bp + b] = itzd;
+    }
+}
+
+// initial state in sample-major layout: x0 (regression), zu = zd = x0, gamma* = 0.1   (ADMM.py:528-544)
+template <bool MASKED>
+__global__ __launch_bounds__(256) void k_init_lds(int T, int t_in, int N, int B, float tm, float den, const float* __restrict__ y,
+                                                  const float* __restrict__ mask, float* __restrict__ x, float* __restrict__ zu,
+                                                  float* __restrict__ zd, float* __restrict__ gam, float* __restrict__ gu,
+                                                  float* __restrict__ gd, int* __restrict__ nonfinite) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= N) return;
+    const size_t sb = (size_t)b * T * N;
+    float w, c0;
+    if (!MASKED) {
+        const float* yb = y + (size_t)b * t_in * N;
+        float sy = 0.f, sty = 0.f;
+        for (int t = 0; t < t_in; ++t) {
+            const float v = yb[t * N + i];
+            sy += v;
+            sty += (float)t * v;
+        }
+        const float ym = sy / (float)t_in;
+        w = (sty / (float)t_in - tm * ym) / den;
+        c0 = ym - w * tm;
+        for (int t = 0; t < T; ++t) {
+            const float v = (t < t_in) ? yb[t * N + i] : w * (float)t + c0;
+            const size_t e = sb + (size_t)t * N + i;
+            x[e] = v; zu[e] = v; zd[e] = v;
+            gam[e] = 0.1f; gu[e] = 0.1f; gd[e] = 0.1f;
+        }
+    } else {
+        const float* yb = y + sb;
+        const float* mb = mask + sb;
+        float n = 0, ts = 0, t2s = 0, ys = 0, tys = 0;
+        for (int t = 0; t < T; ++t) {
+            const float m = mb[t * N + i], v = yb[t * N + i];
+            n += m; ts += (float)t * m; t2s += (float)(t * t) * m;
+            ys += v * m; tys += (float)t * v * m;
+        }
+        const float tmean = ts / n, t2mean = t2s / n, ymean = ys / n, tymean = tys / n;
+        float tm2 = tmean * tmean;
+        asm volatile("" : "+v"(tm2));
+        const float dn = t2mean - tm2;
+        w = (tymean - tmean * ymean) / dn;
+        c0 = ymean - w * tmean;
+        if (!(fabsf(w) <= 3.0e38f) || !(fabsf(c0) <= 3.0e38f)) *nonfinite = 1;
+        for (int t = 0; t < T; ++t) {
+            const float v = (w * (float)t + c0) * (1.f - mb[t * N + i]) + yb[t * N + i];
+            const size_t e = sb + (size_t)t * N + i;
+            x[e] = v; zu[e] = v; zd[e] = v;
+            gam[e] = 0.1f; gu[e] = 0.1f; gd[e] = 0.1f;
+        }
+    }
+}
+
+// delta_x_per_step on the sample-major layout: m2[e] = (mean_b (x - x_old)[b][e])^2, then summed per t
+__global__ __launch_bounds__(256) void k_dxps_sm(int TN, int B, const float* __restrict__ x, const float* __restrict__ xo,
+                                                 double* __restrict__ m2) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= TN) return;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) s += (double)x[(size_t)b * TN + e] - (double)xo[(size_t)b * TN + e];
+    s /= (double)B;
+    m2[e] = s * s;
+}
+
+__global__ void k_dxps_sm_final(int T, int N, const double* __restrict__ m2, double* __restrict__ out) {
+    const int t = blockIdx.x;
+    __shared__ double sm[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) s += m2[(size_t)t * N + i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[t] = sqrt(sm[0]);
+}

@@ -10,6 +10,7 @@
 
 #include "common.h"
 #include "stream_kernels.h"
+#include "lds_kernels.h"
 
 namespace {
 
@@ -56,6 +57,15 @@ struct Engine : EngineBase {
     hipEvent_t ev_ring[LAG + 1] = {nullptr};
     int want_blocks = 2048;
     int64_t ws_bytes = 0;
+    // LDS-resident fused path (float32, small graphs)
+    struct LdsPlan {
+        bool ok = false;
+        int G = 0, TPG = 0, nthreads = 0, block = 0, csr_ints = 0;
+        int off_rp_u = 0, off_rp_d = 0, off_rp_t = 0, off_en_u = 0, off_en_d = 0, off_en_t = 0;
+        size_t lds_bytes = 0;
+    } lds;
+    int* d_lds_csr = nullptr;
+    double* d_m2 = nullptr;
     // profiling
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -71,7 +81,7 @@ struct Engine : EngineBase {
         auto fr = [](void* q) { if (q) (void)hipFree(q); };
         fr(vec_pool); fr(partials); fr(d_rr); fr(d_alpha); fr(d_beta); fr(d_alpha_hist); fr(d_beta_hist);
         fr(d_active); fr(d_iters_tmp); fr(d_nact); fr(d_nonfinite); fr(d_ps); fr(d_hist); fr(d_dxps);
-        fr(d_dxpart); fr(d_hist_ps); fr(d_cg_iters);
+        fr(d_dxpart); fr(d_hist_ps); fr(d_cg_iters); fr(d_lds_csr); fr(d_m2);
         if (h_nact) (void)hipHostFree(h_nact);
         if (h_row) (void)hipHostFree(h_row);
         if (h_flag) (void)hipHostFree(h_flag);
@@ -143,6 +153,7 @@ struct Engine : EngineBase {
         MG_HIP(hipHostMalloc(&h_flag, sizeof(int) * 4));
         for (auto& e : ev_ring) MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         MG_TRY(alloc_iter_dependent());
+        MG_TRY(plan_lds());
         return MGADMM_OK;
     }
 
@@ -154,8 +165,8 @@ struct Engine : EngineBase {
             d_nact = nullptr; d_alpha_hist = d_beta_hist = nullptr; h_nact = nullptr;
             max_cg_alloc = p.max_cg_iter;
             MG_HIP(hipMalloc(&d_nact, sizeof(int) * max_cg_alloc));
-            MG_HIP(hipMalloc(&d_alpha_hist, sizeof(S) * (size_t)max_cg_alloc * Bp_max));
-            MG_HIP(hipMalloc(&d_beta_hist, sizeof(S) * (size_t)max_cg_alloc * Bp_max));
+            MG_HIP(hipMalloc(&d_alpha_hist, sizeof(S) * 3 * (size_t)max_cg_alloc * Bp_max));
+            MG_HIP(hipMalloc(&d_beta_hist, sizeof(S) * 3 * (size_t)max_cg_alloc * Bp_max));
             MG_HIP(hipHostMalloc(&h_nact, sizeof(int) * max_cg_alloc));
         }
         if (p.max_admm_iter > max_admm_alloc) {
@@ -181,7 +192,8 @@ struct Engine : EngineBase {
     }
 
     int64_t workspace_bytes() const override { return ws_bytes; }
-    int path_for(int) const override { return MGADMM_PATH_STREAM; }
+    int path_for(int) const override { return use_lds() ? MGADMM_PATH_LDS : MGADMM_PATH_STREAM; }
+    bool use_lds() const { return lds.ok && p.path != MGADMM_PATH_STREAM; }
 
     // ---------------------------------------------------------------- profiling
     int prof_begin() override {
@@ -538,6 +550,11 @@ struct Engine : EngineBase {
         MG_TRY(check_B(B, "solve"));
         MG_REQUIRE(y && x_out, "solve: null pointer");
         st = s;
+        if (p.path == MGADMM_PATH_LDS && !lds.ok) {
+            mg_set_error("solve: the LDS-resident path needs float32, T*N*8 B + CSR <= 160 KiB and N*G <= 1024 (N=%d, T=%d)", N, T);
+            return MGADMM_ERR_UNSUPPORTED;
+        }
+        if (use_lds()) return solve_lds(y, mask, B, x_out, state_out, hist);
         const Geom q = make_geom(B);
         MG_TRY(ensure_partials(q));
         const size_t ne = velems(q);
@@ -668,6 +685,204 @@ struct Engine : EngineBase {
             if (state_out->gamma_u) MG_TRY(unpack(q, vec[V_GU], state_out->gamma_u));
             if (state_out->gamma_d) MG_TRY(unpack(q, vec[V_GD], state_out->gamma_d));
         }
+        return finish_history(hist, n_done, B, q.Bp, rc_final);
+    }
+
+    // ---------------------------------------------------------------- LDS-resident fused path
+    int plan_lds() {
+        lds = LdsPlan();
+        if (!std::is_same<S, float>::value) return MGADMM_OK;
+        const int tpgs[] = {1, 2, 3, 4, 6, 8, 12};
+        int best = 0;
+        for (int tpg : tpgs) {
+            if (T % tpg) continue;
+            const int G = T / tpg;
+            if ((long)N * G > 1024) continue;
+            if (!best) best = tpg;        // smallest TPG = most threads
+        }
+        if (!best) return MGADMM_OK;
+        const bool band = g->mode == MGADMM_TEMPORAL_BAND;
+        const int nu = g->hWu.nnz(), nd = band ? 0 : g->hWd.nnz(), nt = band ? 0 : g->hWdT.nnz();
+        int off = 0;
+        lds.off_rp_u = off; off += N + 1;
+        lds.off_rp_d = off; off += N + 1;
+        lds.off_rp_t = off; off += N + 1;
+        off += off & 1;
+        lds.off_en_u = off; off += 2 * nu;
+        lds.off_en_d = off; off += 2 * nd;
+        lds.off_en_t = off; off += 2 * nt;
+        lds.csr_ints = off;
+        lds.lds_bytes = (size_t)12 * T * N + 8 + 32 * sizeof(double) + (size_t)4 * off;
+        if (lds.lds_bytes > 160 * 1024) return MGADMM_OK;
+        lds.TPG = best;
+        lds.G = T / best;
+        lds.nthreads = N * lds.G;
+        lds.block = (lds.nthreads + 63) / 64 * 64;
+        std::vector<int> img(off, 0);
+        auto put_csr = [&](const HostCsr& h, int off_rp, int off_en) {
+            for (int i = 0; i <= N; ++i) img[off_rp + i] = h.rowptr[i];
+            for (int e = 0; e < h.nnz(); ++e) {
+                img[off_en + 2 * e] = h.col[e];
+                memcpy(&img[off_en + 2 * e + 1], &h.val[e], 4);
+            }
+        };
+        put_csr(g->hWu, lds.off_rp_u, lds.off_en_u);
+        if (!band) {
+            put_csr(g->hWd, lds.off_rp_d, lds.off_en_d);
+            put_csr(g->hWdT, lds.off_rp_t, lds.off_en_t);
+        }
+        MG_HIP(hipMalloc(&d_lds_csr, sizeof(int) * off));
+        MG_HIP(hipMemcpy(d_lds_csr, img.data(), sizeof(int) * off, hipMemcpyHostToDevice));
+        MG_HIP(hipMalloc(&d_m2, sizeof(double) * T * N));
+        lds.ok = true;
+        return MGADMM_OK;
+    }
+
+    template <int TPG>
+    int launch_lds(const LdsArgs& a, int B) {
+        auto fn = k_admm_lds<TPG>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            MG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        const bool timed = prof_open(0, 0.0);
+        hipLaunchKernelGGL(fn, dim3(B), dim3(lds.block), lds.lds_bytes, st, a);
+        if (timed) prof_close();
+        MG_HIP(hipGetLastError());
+        return MGADMM_OK;
+    }
+
+    int solve_lds(const void* y, const void* mask, int B, void* x_out, const mgadmm_state* state_out, mgadmm_history* hist) {
+        if constexpr (!std::is_same<S, float>::value) {
+            return MGADMM_ERR_UNSUPPORTED;
+        } else {
+            const int abl = p.ablation;
+            const bool has_phi = (abl == MGADMM_ABL_NONE || abl == MGADMM_ABL_DGLR);
+            const bool has_zd = (abl != MGADMM_ABL_DGLR);
+            const int max_it = p.max_admm_iter;
+            const bool record = p.record_cg_coeffs && hist && hist->cg_alpha && hist->cg_beta;
+            const int Bp = (B + 63) / 64 * 64;
+            const size_t TN = (size_t)T * N;
+            if (hist && hist->metrics_per_sample) {
+                size_t need = (size_t)max_it * MGADMM_NMETRIC * B;
+                if (need > hist_ps_elems) {
+                    if (d_hist_ps) MG_HIP(hipFree(d_hist_ps));
+                    d_hist_ps = nullptr;
+                    MG_HIP(hipMalloc(&d_hist_ps, need * sizeof(double)));
+                    hist_ps_elems = need;
+                }
+            }
+            MG_HIP(hipMemsetAsync(d_nonfinite, 0, sizeof(int), st));
+            MG_HIP(hipMemsetAsync(d_ps, 0, sizeof(double) * MGADMM_NMETRIC * Bp, st));
+            MG_HIP(hipMemsetAsync(d_cg_iters, 0, sizeof(int) * (size_t)max_it * 3 * Bp, st));
+            float *xa = vec[V_XA], *xb = vec[V_XB];
+            float *zu = vec[V_ZUA], *zd = vec[V_ZDA], *phi = vec[V_PHIA], *gam = vec[V_GAM], *gu = vec[V_GU], *gd = vec[V_GD];
+            {
+                float tm = 0, t2m = 0;
+                for (int t = 0; t < p.t_in; ++t) { tm += (float)t; t2m += (float)t * (float)t; }
+                tm /= (float)p.t_in;
+                t2m /= (float)p.t_in;
+                const float den = t2m - tm * tm;
+                dim3 grid((N + 255) / 256, B);
+                if (mask)
+                    hipLaunchKernelGGL((k_init_lds<true>), grid, dim3(256), 0, st, T, p.t_in, N, B, tm, den, (const float*)y,
+                                       (const float*)mask, xa, zu, zd, gam, gu, gd, d_nonfinite);
+                else
+                    hipLaunchKernelGGL((k_init_lds<false>), grid, dim3(256), 0, st, T, p.t_in, N, B, tm, den, (const float*)y,
+                                       (const float*)nullptr, xa, zu, zd, gam, gu, gd, d_nonfinite);
+                MG_HIP(hipGetLastError());
+            }
+            LdsArgs a{};
+            a.T = T; a.N = N; a.TN = (int)TN; a.t_in = p.t_in; a.G = lds.G; a.B = B; a.Bp = Bp;
+            a.nthreads = lds.nthreads;
+            a.has_phi = has_phi; a.has_zd = has_zd;
+            const LhsDef dx = lhs_def(MGADMM_LHS_X);
+            a.lhsx_kind = dx.kind == 1 ? 1 : 0;
+            a.cx1 = (float)dx.c1; a.cx2 = (float)dx.c2;
+            a.band = g->mode == MGADMM_TEMPORAL_BAND; a.skip = g->skip;
+            a.q1 = a.band ? 0 : g->q1;
+            a.max_cg = p.max_cg_iter; a.record = record ? 1 : 0;
+            a.rho = (float)p.rho; a.rho_u = (float)p.rho_u; a.rho_d = (float)p.rho_d;
+            a.mu_u = (float)p.mu_u; a.mu_d1 = (float)p.mu_d1; a.mu_d2 = (float)p.mu_d2;
+            a.cg_tol = p.cg_tol;
+            a.csr = d_lds_csr; a.csr_ints = lds.csr_ints;
+            a.off_rp_u = lds.off_rp_u; a.off_rp_d = lds.off_rp_d; a.off_rp_t = lds.off_rp_t;
+            a.off_en_u = lds.off_en_u; a.off_en_d = lds.off_en_d; a.off_en_t = lds.off_en_t;
+            a.band_w = g->band_w;
+            a.zu = zu; a.zd = zd; a.phi = phi; a.gam = gam; a.gu = gu; a.gd = gd;
+            a.y = (const float*)y; a.mask = (const float*)mask;
+            a.ps = d_ps; a.alpha_hist = record ? (float*)d_alpha_hist : nullptr; a.beta_hist = record ? (float*)d_beta_hist : nullptr;
+            a.nonfinite = d_nonfinite;
+            const size_t K = p.max_cg_iter;
+            int n_done = 0, rc_final = MGADMM_OK;
+            float *xc = xa, *xn = xb;
+            for (int it = 0; it < max_it; ++it) {
+                a.first = it == 0;
+                a.x_old = xc; a.x_new = xn;
+                a.cg_iters = d_cg_iters + (size_t)it * 3 * Bp;
+                if (record) {
+                    MG_TRY(fill((S*)d_alpha_hist, 3 * K * Bp, (S)NAN));
+                    MG_TRY(fill((S*)d_beta_hist, 3 * K * Bp, (S)NAN));
+                }
+                switch (lds.TPG) {
+                    case 1: MG_TRY(launch_lds<1>(a, B)); break;
+                    case 2: MG_TRY(launch_lds<2>(a, B)); break;
+                    case 3: MG_TRY(launch_lds<3>(a, B)); break;
+                    case 4: MG_TRY(launch_lds<4>(a, B)); break;
+                    case 6: MG_TRY(launch_lds<6>(a, B)); break;
+                    case 8: MG_TRY(launch_lds<8>(a, B)); break;
+                    case 12: MG_TRY(launch_lds<12>(a, B)); break;
+                    default: mg_set_error("solve_lds: bad TPG"); return MGADMM_ERR_UNSUPPORTED;
+                }
+                hipLaunchKernelGGL(k_dxps_sm, dim3(((int)TN + 255) / 256), dim3(256), 0, st, (int)TN, B, (const float*)xn,
+                                   (const float*)xc, d_m2);
+                hipLaunchKernelGGL(k_dxps_sm_final, dim3(T), dim3(256), 0, st, T, N, (const double*)d_m2, d_dxps + (size_t)it * T);
+                hipLaunchKernelGGL(k_batch_metrics, dim3(MGADMM_NMETRIC), dim3(256), 0, st, (const double*)d_ps, Bp, B,
+                                   d_hist + (size_t)it * MGADMM_NMETRIC,
+                                   (hist && hist->metrics_per_sample) ? d_hist_ps + (size_t)it * MGADMM_NMETRIC * B : nullptr);
+                MG_HIP(hipGetLastError());
+                if (record) {
+                    for (int w = 0; w < 3; ++w) {
+                        if (w == 2 && !has_zd) continue;
+                        double* ao = hist->cg_alpha + ((size_t)it * 3 + w) * K * B;
+                        double* bo = hist->cg_beta + ((size_t)it * 3 + w) * K * B;
+                        MG_TRY(fetch_hist(d_alpha_hist + (size_t)w * K * Bp, K * Bp, ao, B, Bp, K));
+                        MG_TRY(fetch_hist(d_beta_hist + (size_t)w * K * Bp, K * Bp, bo, B, Bp, K));
+                    }
+                }
+                std::swap(xc, xn);
+                n_done = it + 1;
+                if (p.check_stop) {
+                    MG_HIP(hipMemcpyAsync(h_row, d_hist + (size_t)it * MGADMM_NMETRIC, sizeof(double) * MGADMM_NMETRIC,
+                                          hipMemcpyDeviceToHost, st));
+                    MG_HIP(hipMemcpyAsync(h_flag, d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+                    MG_HIP(hipStreamSynchronize(st));
+                    bool finite = h_flag[0] == 0;
+                    for (int k = 0; k < MGADMM_NMETRIC; ++k) finite = finite && std::isfinite(h_row[k]);
+                    if (!finite) { rc_final = MGADMM_ERR_NONFINITE; break; }
+                    double pri = h_row[MGADMM_M_PRI_ZU], dual = h_row[MGADMM_M_DUAL_ZU];
+                    if (has_phi) { pri = std::max(pri, h_row[MGADMM_M_PRI_PHI]); dual = std::max(dual, h_row[MGADMM_M_DUAL_PHI]); }
+                    if (has_zd) { pri = std::max(pri, h_row[MGADMM_M_PRI_ZD]); dual = std::max(dual, h_row[MGADMM_M_DUAL_ZD]); }
+                    if (pri < p.admm_tol && dual < p.admm_tol) break;
+                }
+            }
+            const size_t bytes = (size_t)B * TN * sizeof(float);
+            MG_HIP(hipMemcpyAsync(x_out, xc, bytes, hipMemcpyDeviceToDevice, st));
+            if (state_out) {
+                if (state_out->zu) MG_HIP(hipMemcpyAsync(state_out->zu, zu, bytes, hipMemcpyDeviceToDevice, st));
+                if (state_out->zd) MG_HIP(hipMemcpyAsync(state_out->zd, zd, bytes, hipMemcpyDeviceToDevice, st));
+                if (state_out->phi && has_phi) MG_HIP(hipMemcpyAsync(state_out->phi, phi, bytes, hipMemcpyDeviceToDevice, st));
+                if (state_out->gamma && has_phi) MG_HIP(hipMemcpyAsync(state_out->gamma, gam, bytes, hipMemcpyDeviceToDevice, st));
+                if (state_out->gamma_u) MG_HIP(hipMemcpyAsync(state_out->gamma_u, gu, bytes, hipMemcpyDeviceToDevice, st));
+                if (state_out->gamma_d) MG_HIP(hipMemcpyAsync(state_out->gamma_d, gd, bytes, hipMemcpyDeviceToDevice, st));
+            }
+            return finish_history(hist, n_done, B, Bp, rc_final);
+        }
+    }
+
+    // copies the device-side history of a finished solve into the caller's host buffers
+    int finish_history(mgadmm_history* hist, int n_done, int B, int Bp, int rc_final) {
         if (hist) {
             hist->n_iters = n_done;
             if (hist->metrics)
@@ -678,11 +893,11 @@ struct Engine : EngineBase {
                 MG_HIP(hipMemcpyAsync(hist->metrics_per_sample, d_hist_ps, sizeof(double) * (size_t)n_done * MGADMM_NMETRIC * B,
                                       hipMemcpyDeviceToHost, st));
             if (hist->cg_iters) {
-                std::vector<int> tmp((size_t)n_done * 3 * q.Bp);
+                std::vector<int> tmp((size_t)n_done * 3 * Bp);
                 MG_HIP(hipMemcpyAsync(tmp.data(), d_cg_iters, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost, st));
                 MG_HIP(hipStreamSynchronize(st));
                 for (size_t r = 0; r < (size_t)n_done * 3; ++r)
-                    memcpy(hist->cg_iters + r * B, tmp.data() + r * q.Bp, sizeof(int) * B);
+                    memcpy(hist->cg_iters + r * B, tmp.data() + r * Bp, sizeof(int) * B);
             }
         }
         MG_HIP(hipMemcpyAsync(h_flag, d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));

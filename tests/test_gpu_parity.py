@@ -262,11 +262,11 @@ def check_solve(blk, key, G, abl, x, xtol, htol, it_slack):
     assert torch.Tensor(blk.p_res_list).shape == (n, len(blk.res_name))     # what plot_residual reads
 
 
-def run_case(meta, solves, key, compute_dtype):
+def run_case(meta, solves, key, compute_dtype, path="auto"):
     mode, abl, task, tag, iters = key.split("-")
     np_dt = np.float64 if tag == "f64" else np.float32
     y, mask = case_inputs(meta, task, np_dt)
-    blk = make_product(meta, mode, ablation=abl, compute_dtype=compute_dtype)
+    blk = make_product(meta, mode, ablation=abl, compute_dtype=compute_dtype, path=path)
     blk.max_ADMM_iter = int(iters)
     yt = torch.from_numpy(y)
     mt = torch.from_numpy(mask) if mask is not None else None      # float32 mask like utils.py:129
@@ -298,13 +298,16 @@ def test_full_solves_f64_kernels_vs_reference_f64(g4_meta, g4_solves):
     assert n >= 30
 
 
-def test_full_solves_f32_kernels_vs_reference_f64(g4_meta, g4_solves):
+@pytest.mark.parametrize("path", ["lds", "stream"])
+def test_full_solves_f32_kernels_vs_reference_f64(g4_meta, g4_solves, path):
     """The product's default arithmetic (float32 HIP) against the reference's float64 iterates,
-    float64 inputs: the tolerance sweep of BASELINE config 5 at fixture size."""
+    float64 inputs: the tolerance sweep of BASELINE config 5 at fixture size.  Both execution paths:
+    the LDS-resident fused kernel (one workgroup per sample) and the streaming batch-innermost kernels."""
     n = 0
     for key in all_keys(g4_solves, "f64"):
         abl = key.split("-")[1]
-        blk, x, zu, zd, phi = run_case(g4_meta, g4_solves, key, torch.float32)
+        blk, x, zu, zd, phi = run_case(g4_meta, g4_solves, key, torch.float32, path)
+        assert rel(zu, g4_solves[f"{key}/zu"]) < 1e-4
         G = lambda f: g4_solves[f"{key}/{f}"]
         check_solve(blk, key, G, abl, x, F32_X_TOL, F32_HIST_RTOL, 1)
         blk.close()
@@ -325,11 +328,13 @@ def test_full_solves_f32_inputs(g4_meta, g4_solves):
     assert n >= 30
 
 
-@pytest.mark.parametrize("dt,xtol,htol,slack", [(torch.float64, 1e-10, 1e-8, 0), (torch.float32, 1e-5, 1e-3, 1)])
-def test_batched_equals_looped_reference_runs(dt, xtol, htol, slack):
+@pytest.mark.parametrize("dt,xtol,htol,slack,path", [(torch.float64, 1e-10, 1e-8, 0, "stream"),
+                                                       (torch.float32, 1e-5, 1e-3, 1, "stream"),
+                                                       (torch.float32, 1e-5, 1e-3, 1, "lds")])
+def test_batched_equals_looped_reference_runs(dt, xtol, htol, slack, path):
     g = load_golden("g5_batched.npz")
     meta = load_golden("g4_meta.npz")
-    blk = make_product(meta, "knn", compute_dtype=dt)
+    blk = make_product(meta, "knn", compute_dtype=dt, path=path)
     blk.max_ADMM_iter = int(g["iters"])
     x, (zu, zd), phi, hist = blk.solve(T_(g["y"]), per_sample_history=True)
     assert rel(x, g["x"]) < xtol
@@ -349,10 +354,11 @@ def test_batched_equals_looped_reference_runs(dt, xtol, htol, slack):
     blk.close()
 
 
-def test_solve_is_bitwise_repeatable_and_inputs_untouched():
+@pytest.mark.parametrize("path", ["lds", "stream"])
+def test_solve_is_bitwise_repeatable_and_inputs_untouched(path):
     meta = load_golden("g4_meta.npz")
     g = load_golden("g5_batched.npz")
-    blk = make_product(meta, "knn")
+    blk = make_product(meta, "knn", path=path)
     blk.max_ADMM_iter = 5
     y = T_(g["y"], torch.float32)
     y0 = y.clone()
@@ -408,4 +414,33 @@ def test_print_info_format(capsys):
     blk.combined_loop(torch.from_numpy(y), print_info=True)
     out = capsys.readouterr().out.strip().splitlines()
     assert len(out) == 2 and out[0].startswith("ADMM iters 0: x_CG_iters ") and "pri_err = [" in out[0]
+    blk.close()
+
+
+def test_lds_path_selection_and_cg_coefficients():
+    """path='auto' takes the LDS-resident kernel for PEMS-size float32 problems and the streaming kernels
+    otherwise; both record the CG coefficients like alpha_x / beta_x of the reference (example.ipynb cell 10)."""
+    from mgadmm import _lib
+    meta = load_golden("g4_meta.npz")
+    g4 = load_golden("g4_solves.npz")
+    y, _ = case_inputs(meta, "pred", np.float64)
+    res = {}
+    for path in ("lds", "stream"):
+        blk = make_product(meta, "knn", path=path)
+        blk.max_ADMM_iter = 3
+        blk.combined_loop(torch.from_numpy(y), print_info=False)
+        h = blk._solvers[(1, torch.float32)][0]
+        assert _lib.lib.mgadmm_solver_path(h, 1) == (_lib.PATH_LDS if path == "lds" else _lib.PATH_STREAM)
+        res[path] = blk
+        a0 = blk.alpha_x[0].numpy()
+        ref = g4["knn-None-pred-f64-5/alpha_x"][0]
+        n = min(len(a0), int(np.isfinite(ref).sum()))
+        np.testing.assert_allclose(a0[:n - 1], ref[:n - 1], rtol=2e-3)
+        assert len(blk.alpha_zd) == 3 and len(blk.beta_zu) == 3
+    np.testing.assert_allclose(np.array(res["lds"].p_res_list), np.array(res["stream"].p_res_list), rtol=1e-4)
+    for b in res.values():
+        b.close()
+    blk = make_product(meta, "knn", compute_dtype=torch.float64, path="lds")
+    with pytest.raises(_lib.MgadmmError):
+        blk.combined_loop(torch.from_numpy(y), print_info=False)
     blk.close()
