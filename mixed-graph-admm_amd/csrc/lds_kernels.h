@@ -45,30 +45,86 @@ struct LdsArgs {
     int* nonfinite;
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// wave64 sum with DPP row shifts / row broadcasts (no LDS traffic); the total ends up in lane 63 and is
+// broadcast with readlane.  Fixed association order -> bitwise repeatable.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_step(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_step<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_step<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_step<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_step<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row total
+    v = dpp_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// Fixed-order workgroup sum; `red` has 2 x 16 doubles used alternately (one barrier per call).
+// Fixed-order workgroup sum: per-wave float totals (DPP) -> 16 LDS slots -> every thread adds the 16 slots
+// in double.  `red` holds 2 x 16 floats used alternately, so one barrier per call is enough.
 struct BlockRed {
-    double* red;
+    float* red;
     int par;
     int lane, wave, nwaves;
-    __device__ __forceinline__ double sum(double v) {
+    __device__ __forceinline__ double sum(float v) {
         v = wave_sum(v);
-        double* buf = red + par * 16;
+        float* buf = red + par * 16;
         if (lane == 0) buf[wave] = v;
         __syncthreads();
-        double s = 0.0;
-        for (int w = 0; w < nwaves; ++w) s += buf[w];
+        const float4 a = reinterpret_cast<const float4*>(buf)[0], b = reinterpret_cast<const float4*>(buf)[1],
+                     c = reinterpret_cast<const float4*>(buf)[2], d = reinterpret_cast<const float4*>(buf)[3];
+        double s = (double)a.x;
+        s += (double)a.y; s += (double)a.z; s += (double)a.w;
+        s += (double)b.x; s += (double)b.y; s += (double)b.z; s += (double)b.w;
+        s += (double)c.x; s += (double)c.y; s += (double)c.z; s += (double)c.w;
+        s += (double)d.x; s += (double)d.y; s += (double)d.z; s += (double)d.w;
         par ^= 1;
         return s;
     }
 };
 
+// vector access to TPG consecutive floats in LDS (alignment: TPG*4 B when TPG is a multiple of 4, 8 B when
+// even -- guaranteed by the node-major [N][T] LDS layout with TPG | T)
 template <int TPG>
+__device__ __forceinline__ void lds_load(const float* p, float (&v)[TPG]) {
+    if constexpr (TPG % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < TPG / 4; ++j) {
+            const float4 q = reinterpret_cast<const float4*>(p)[j];
+            v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+        }
+    } else if constexpr (TPG % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < TPG / 2; ++j) {
+            const float2 q = reinterpret_cast<const float2*>(p)[j];
+            v[2 * j] = q.x; v[2 * j + 1] = q.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TPG; ++j) v[j] = p[j];
+    }
+}
+template <int TPG>
+__device__ __forceinline__ void lds_store(float* p, const float (&v)[TPG]) {
+    if constexpr (TPG % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < TPG / 4; ++j) reinterpret_cast<float4*>(p)[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    } else if constexpr (TPG % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < TPG / 2; ++j) reinterpret_cast<float2*>(p)[j] = make_float2(v[2 * j], v[2 * j + 1]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < TPG; ++j) p[j] = v[j];
+    }
+}
+
+// Per-thread view: node i, time steps t0 .. t0+TPG-1.
+//   LDS vectors are node-major, time innermost: A[node*T + t]  -> the TPG time steps of any node are one
+//   contiguous, aligned run (vector ds_read), also for a gathered neighbour;
+//   HBM state is the reference's (T, N) order per sample: element (t, i) at t*N + i (coalesced over i).
+template <int TPG, bool BAND>
 struct LdsCtx {
     int T, N, t0, i;
     bool active;
@@ -77,76 +133,102 @@ struct LdsCtx {
     float* AP;
     const int2* en_u; const int2* en_d; const int2* en_t;
     int u0, u1, d0, d1, t0e, t1e;   // this node's CSR row bounds
-    int band, skip, q1;
+    int skip, q1;
     const float* band_w;
 
-    __device__ __forceinline__ int el(int k) const { return (t0 + k) * N + i; }
+    __device__ __forceinline__ int gl(int k) const { return (t0 + k) * N + i; }   // HBM index
+    __device__ __forceinline__ int own() const { return i * T + t0; }             // LDS index of element k = 0
 
-    // acc[k] = sum_e w_e * SRC[(t0+k+shift)*N + col_e]
+    // acc[k] = sum_e w_e * SRC[col_e][t0+k+shift]     (0 outside [0,T))
     __device__ __forceinline__ void gather(const float* SRC, const int2* EN, int e0, int e1, int shift, float (&acc)[TPG]) const {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
+        int2 nx = EN[e0];                   // one entry ahead (arrays are padded: reading EN[e1] is safe)
         for (int e = e0; e < e1; ++e) {
-            const int2 en = EN[e];
+            const int2 en = nx;
+            nx = EN[e + 1];
             const float w = __int_as_float(en.y);
+            const float* row = SRC + en.x * T + t0;
+            float v[TPG];
+            lds_load<TPG>(row, v);
+            if (shift == 0) {
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) {
-                const int tt = t0 + k + shift;
-                if (tt >= 0 && tt < T) acc[k] += w * SRC[tt * N + en.x];
+                for (int k = 0; k < TPG; ++k) acc[k] += w * v[k];
+            } else if (shift < 0) {
+                const float edge = (t0 > 0) ? row[-1] : 0.f;
+                acc[0] += w * edge;
+#pragma unroll
+                for (int k = 1; k < TPG; ++k) acc[k] += w * v[k - 1];
+            } else {
+                const float edge = (t0 + TPG < T) ? row[TPG] : 0.f;
+#pragma unroll
+                for (int k = 0; k < TPG - 1; ++k) acc[k] += w * v[k + 1];
+                acc[TPG - 1] += w * edge;
             }
         }
     }
-    // l = Lu(src): src values of the own elements in `self`, neighbours from SRC (LDS)     ADMM.py:138-148
-    __device__ __forceinline__ void op_lu(const float* SRC, float (&l)[TPG]) const {
-        float acc[TPG];
-        gather(SRC, en_u, u0, u1, 0, acc);
+    // band (line-graph) stencils on the node's own time row
+    __device__ __forceinline__ void band_back(const float* SRC, float (&acc)[TPG]) const {
+        const float* row = SRC + i * T;
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) l[k] = SRC[el(k)] - acc[k];
+        for (int k = 0; k < TPG; ++k) {
+            acc[k] = 0.f;
+            const int t = t0 + k;
+            for (int s = 0; s < skip; ++s) {
+                const int tt = t - 1 - s;
+                if (tt < 0) break;
+                acc[k] += band_w[t * skip + s] * row[tt];
+            }
+        }
+    }
+    __device__ __forceinline__ void band_fwd(const float* SRC, float (&acc)[TPG]) const {
+        const float* row = SRC + i * T;
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            acc[k] = 0.f;
+            const int t = t0 + k;
+            for (int s = 0; s < skip; ++s) {
+                const int tt = t + 1 + s;
+                if (tt >= T) break;
+                acc[k] += band_w[tt * skip + s] * row[tt];
+            }
+        }
+    }
+    // l = Lu(src): own elements and neighbours both from SRC (LDS)     ADMM.py:138-148
+    __device__ __forceinline__ void op_lu(const float* SRC, float (&l)[TPG]) const {
+        float acc[TPG], self[TPG];
+        gather(SRC, en_u, u0, u1, 0, acc);
+        lds_load<TPG>(SRC + own(), self);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) l[k] = self[k] - acc[k];
     }
     // l = Ldr(src)      ADMM.py:150-177
     __device__ __forceinline__ void op_ldr(const float* SRC, float (&l)[TPG]) const {
-        float acc[TPG];
-        if (!band) {
-            gather(SRC, en_d, d0, d1, -1, acc);
-        } else {
+        float acc[TPG], self[TPG];
+        if constexpr (!BAND) gather(SRC, en_d, d0, d1, -1, acc);
+        else band_back(SRC, acc);
+        lds_load<TPG>(SRC + own(), self);
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) {
-                acc[k] = 0.f;
-                const int t = t0 + k;
-                for (int s = 0; s < skip; ++s) {
-                    const int tt = t - 1 - s;
-                    if (tt < 0) break;
-                    acc[k] += band_w[t * skip + s] * SRC[tt * N + i];
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < TPG; ++k) l[k] = ((t0 + k >= 1) ? SRC[el(k)] : 0.f) - acc[k];
+        for (int k = 0; k < TPG; ++k) l[k] = ((t0 + k >= 1) ? self[k] : 0.f) - acc[k];
     }
     // l = Ldr_T(src)    ADMM.py:179-223 (q1: identity kept on the t=0 block)
     __device__ __forceinline__ void op_ldrt(const float* SRC, float (&l)[TPG]) const {
-        float acc[TPG];
-        if (!band) {
-            gather(SRC, en_t, t0e, t1e, +1, acc);
-        } else {
+        float acc[TPG], self[TPG];
+        if constexpr (!BAND) gather(SRC, en_t, t0e, t1e, +1, acc);
+        else band_fwd(SRC, acc);
+        lds_load<TPG>(SRC + own(), self);
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) {
-                acc[k] = 0.f;
-                const int t = t0 + k;
-                for (int s = 0; s < skip; ++s) {
-                    const int tt = t + 1 + s;
-                    if (tt >= T) break;
-                    acc[k] += band_w[tt * skip + s] * SRC[tt * N + i];
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < TPG; ++k) l[k] = ((t0 + k > 0 || q1) ? SRC[el(k)] : 0.f) - acc[k];
+        for (int k = 0; k < TPG; ++k) l[k] = ((t0 + k > 0 || q1) ? self[k] : 0.f) - acc[k];
     }
+    // own elements -> LDS vector
     __device__ __forceinline__ void put(float* DST, const float (&v)[TPG]) const {
+        if (active) lds_store<TPG>(DST + own(), v);
+    }
+    // own elements -> HBM state vector (sample base already applied)
+    __device__ __forceinline__ void putg(float* DST, const float (&v)[TPG]) const {
         if (active) {
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) DST[el(k)] = v[k];
+            for (int k = 0; k < TPG; ++k) DST[gl(k)] = v[k];
         }
     }
 };
@@ -156,8 +238,8 @@ struct LdsCtx {
 // d = dg[el] when dg != nullptr (mask values, global memory), else [hth && t < t_in].
 // Own elements of the result go to ctx.AP (LDS); returns sum_k v_k * (A v)_k of the own elements.
 // Uses ctx.Q as scratch; contains a barrier for KIND 1.  Callers separate successive calls by barriers.
-template <int TPG, int KIND>
-__device__ __forceinline__ double lds_apply(const LdsCtx<TPG>& c, const float* dg, int hth, int t_in, float c1, float c2) {
+template <int TPG, bool BAND, int KIND>
+__device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND>& c, const float* dg, int hth, int t_in, float c1, float c2) {
     float l[TPG];
 #pragma unroll
     for (int k = 0; k < TPG; ++k) l[k] = 0.f;
@@ -172,18 +254,18 @@ __device__ __forceinline__ double lds_apply(const LdsCtx<TPG>& c, const float* d
     } else if (KIND == 2) {
         if (c.active) c.op_lu(c.P, l);
     }
-    double part = 0.0;
+    float part = 0.f;
     if (c.active) {
+        float v[TPG], av[TPG];
+        lds_load<TPG>(c.P + c.own(), v);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
-            const int e = c.el(k);
-            const float v = c.P[e];
             float d = 0.f;
-            if (KIND != 2) d = dg ? dg[e] : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
-            const float av = d * v + c1 * v + c2 * l[k];
-            c.AP[e] = av;
-            part += (double)v * (double)av;
+            if (KIND != 2) d = dg ? dg[c.gl(k)] : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
+            av[k] = d * v[k] + c1 * v[k] + c2 * l[k];
+            part += v[k] * av[k];
         }
+        lds_store<TPG>(c.AP + c.own(), av);
     }
     return part;
 }
@@ -192,8 +274,8 @@ __device__ __forceinline__ double lds_apply(const LdsCtx<TPG>& c, const float* d
 // p in LDS (ctx.P), A p in LDS (ctx.AP).  x holds x0 on entry and the solution on exit.  dmask: diagonal
 // of the initial residual when a mask is given (global memory); the iterations always use [t<t_in]
 // (quirk Q2).  Returns the iteration count (k+1) or -1.  Entry requirement: no thread still reads P/Q.
-template <int TPG, int KIND>
-__device__ __forceinline__ int lds_cg(const LdsCtx<TPG>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
+template <int TPG, bool BAND, int KIND>
+__device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
                       int hth, int t_in, float c1, float c2, int max_cg, double tol, float* ah, float* bh, int Bp,
                       int* nonfinite) {
     float r[TPG];
@@ -201,13 +283,15 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG>& c, BlockRed& br, float 
     for (int k = 0; k < TPG; ++k) r[k] = 0.f;
     c.put(c.P, x);
     __syncthreads();
-    (void)lds_apply<TPG, KIND>(c, dmask, hth, t_in, c1, c2);
-    double part = 0.0;
+    (void)lds_apply<TPG, BAND, KIND>(c, dmask, hth, t_in, c1, c2);
+    float part = 0.f;
     if (c.active) {
+        float av[TPG];
+        lds_load<TPG>(c.AP + c.own(), av);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
-            r[k] = rhs[k] - c.AP[c.el(k)];
-            part += (double)r[k] * (double)r[k];
+            r[k] = rhs[k] - av[k];
+            part += r[k] * r[k];
         }
     }
     float rr = (float)br.sum(part);      // barrier: every read of P (= x0) is done
@@ -215,17 +299,19 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG>& c, BlockRed& br, float 
     int iters = -1;
     for (int it = 0; it < max_cg; ++it) {
         __syncthreads();                 // p complete in LDS
-        part = lds_apply<TPG, KIND>(c, nullptr, hth, t_in, c1, c2);
+        part = lds_apply<TPG, BAND, KIND>(c, nullptr, hth, t_in, c1, c2);
         const float pAp = (float)br.sum(part);   // barrier: every gather from P/Q of this iteration is done
         const float alpha = rr / pAp;
-        part = 0.0;
+        part = 0.f;
         if (c.active) {
+            float pv[TPG], av[TPG];
+            lds_load<TPG>(c.P + c.own(), pv);
+            lds_load<TPG>(c.AP + c.own(), av);
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
-                const int e = c.el(k);
-                x[k] = x[k] + alpha * c.P[e];
-                r[k] = r[k] - alpha * c.AP[e];
-                part += (double)r[k] * (double)r[k];
+                x[k] = x[k] + alpha * pv[k];
+                r[k] = r[k] - alpha * av[k];
+                part += r[k] * r[k];
             }
         }
         const float rrn = (float)br.sum(part);
@@ -244,48 +330,55 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG>& c, BlockRed& br, float 
             break;
         }
         if (c.active) {
+            float pv[TPG];
+            lds_load<TPG>(c.P + c.own(), pv);
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) {
-                const int e = c.el(k);
-                c.P[e] = r[k] + beta * c.P[e];
-            }
+            for (int k = 0; k < TPG; ++k) pv[k] = r[k] + beta * pv[k];
+            lds_store<TPG>(c.P + c.own(), pv);
         }
     }
     return iters;
 }
 
-template <int TPG>
+template <int TPG, bool BAND>
 __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     float* P = reinterpret_cast<float*>(lds_raw);
     float* Q = P + a.TN;
     float* AP = Q + a.TN;
-    double* red = reinterpret_cast<double*>(AP + a.TN + (a.TN & 1));  // 8-byte aligned
+    float* red = AP + a.TN + ((4 - (a.TN & 3)) & 3);                   // 16-byte aligned, 2 x 16 floats
     int* csr = reinterpret_cast<int*>(red + 32);
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
     for (int k = tid; k < a.csr_ints; k += blockDim.x) csr[k] = a.csr[k];
+    if (tid < 32) red[tid] = 0.f;          // slots of non-existent waves must read as 0
 
-    LdsCtx<TPG> c;
+    LdsCtx<TPG, BAND> c;
     c.T = a.T; c.N = a.N;
     c.active = tid < a.nthreads;
     const int g = c.active ? tid / a.N : 0;
     c.i = c.active ? tid - g * a.N : 0;
     c.t0 = g * TPG;
     c.P = P; c.Q = Q; c.AP = AP;
-    c.band = a.band; c.skip = a.skip; c.q1 = a.q1; c.band_w = a.band_w;
+    c.skip = a.skip; c.q1 = a.q1; c.band_w = a.band_w;
     c.en_u = reinterpret_cast<const int2*>(csr + a.off_en_u);
     c.en_d = reinterpret_cast<const int2*>(csr + a.off_en_d);
     c.en_t = reinterpret_cast<const int2*>(csr + a.off_en_t);
     __syncthreads();
     c.u0 = csr[a.off_rp_u + c.i]; c.u1 = csr[a.off_rp_u + c.i + 1];
     c.d0 = c.d1 = c.t0e = c.t1e = 0;
-    if (!a.band) {
+    if (!BAND) {
         c.d0 = csr[a.off_rp_d + c.i]; c.d1 = csr[a.off_rp_d + c.i + 1];
         c.t0e = csr[a.off_rp_t + c.i]; c.t1e = csr[a.off_rp_t + c.i + 1];
     }
     BlockRed br;
     br.red = red; br.par = 0; br.lane = tid & 63; br.wave = tid >> 6; br.nwaves = (blockDim.x + 63) >> 6;
+    // per-sample metric sums are reduced and stored as soon as they are known (keeps no accumulator alive
+    // across the CG solves); the whole-batch values are formed by k_batch_metrics
+    auto emit = [&](int m, double v, bool keep) {
+        const double sres = br.sum((float)v);
+        if (tid == 0) a.ps[(size_t)m * a.Bp + b] = keep ? sres : 0.0;
+    };
 
     const size_t sb = (size_t)b * a.TN;
     const float* xo = a.x_old + sb;
@@ -297,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
 
     float x[TPG];
 #pragma unroll
-    for (int k = 0; k < TPG; ++k) x[k] = c.active ? xo[c.el(k)] : 0.f;
+    for (int k = 0; k < TPG; ++k) x[k] = c.active ? xo[c.gl(k)] : 0.f;
 
     // ---- first iteration only: phi = Ldr x0 (ADMM.py:541); the dual variables were filled by k_init_lds
     if (a.has_phi && a.first) {
@@ -307,7 +400,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
         c.put(P, x);
         __syncthreads();
         if (c.active) c.op_ldr(P, ph);
-        c.put(phi, ph);
+        c.putg(phi, ph);
         __syncthreads();
     }
 
@@ -320,7 +413,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
         if (a.has_phi) {
             float v[TPG];
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) v[k] = c.active ? gam[c.el(k)] + a.rho * phi[c.el(k)] : 0.f;
+            for (int k = 0; k < TPG; ++k) v[k] = c.active ? gam[c.gl(k)] + a.rho * phi[c.gl(k)] : 0.f;
             c.put(P, v);
             __syncthreads();
             if (c.active) c.op_ldrt(P, l);
@@ -330,7 +423,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
         for (int k = 0; k < TPG; ++k) {
             rhs[k] = 0.f;
             if (c.active) {
-                const int e = c.el(k);
+                const int e = c.gl(k);
                 const int t = c.t0 + k;
                 const float yv = (t < ty) ? yb[t * a.N + c.i] : 0.f;
                 float o;
@@ -346,25 +439,29 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
 
     // ---- x solve (ADMM.py:571)
     int itx;
-    if (a.lhsx_kind == 1) itx = lds_cg<TPG, 1>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, a.cx2, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
-    else itx = lds_cg<TPG, 0>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, 0.f, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
-    c.put(xn, x);
+    if (a.lhsx_kind == 1) itx = lds_cg<TPG, BAND, 1>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, a.cx2, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
+    else itx = lds_cg<TPG, BAND, 0>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, 0.f, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
+    c.putg(xn, x);
 
-    double m_xshift = 0, m_prizu = 0, m_dualzu = 0, m_prizd = 0, m_dualzd = 0, m_rec = 0;
-    if (c.active) {
+    {
+        double m_xshift = 0, m_rec = 0;
+        if (c.active) {
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) {
-            const int t = c.t0 + k;
-            const double dx = (double)x[k] - (double)xo[c.el(k)];
-            m_xshift += dx * dx;
-            if (mk) {
-                const double e = (double)(x[k] * mk[c.el(k)] - yb[t * a.N + c.i]);
-                m_rec += e * e;
-            } else if (t < a.t_in) {
-                const double e = (double)(x[k] - yb[t * a.N + c.i]);
-                m_rec += e * e;
+            for (int k = 0; k < TPG; ++k) {
+                const int t = c.t0 + k;
+                const double dx = (double)x[k] - (double)xo[c.gl(k)];
+                m_xshift += dx * dx;
+                if (mk) {
+                    const double e = (double)(x[k] * mk[c.gl(k)] - yb[t * a.N + c.i]);
+                    m_rec += e * e;
+                } else if (t < a.t_in) {
+                    const double e = (double)(x[k] - yb[t * a.N + c.i]);
+                    m_rec += e * e;
+                }
             }
         }
+        emit(MGADMM_M_XSHIFT, m_xshift, true);
+        emit(MGADMM_M_RECOVER, m_rec, true);
     }
 
     // ---- zu solve + gamma_u update (ADMM.py:579-580, 595)
@@ -375,16 +472,17 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
         for (int k = 0; k < TPG; ++k) {
             z[k] = 0.f;
             if (c.active) {
-                z[k] = zu[c.el(k)];
-                rhs[k] = gu[c.el(k)] / 2.f + a.rho_u / 2.f * xn[c.el(k)];
+                z[k] = zu[c.gl(k)];
+                rhs[k] = gu[c.gl(k)] / 2.f + a.rho_u / 2.f * xn[c.gl(k)];
             }
         }
-        itzu = lds_cg<TPG, 2>(c, br, z, rhs, nullptr, 0, 0, a.rho_u / 2.f, a.mu_u, a.max_cg, a.cg_tol, ah ? ah + hstride : nullptr,
+        itzu = lds_cg<TPG, BAND, 2>(c, br, z, rhs, nullptr, 0, 0, a.rho_u / 2.f, a.mu_u, a.max_cg, a.cg_tol, ah ? ah + hstride : nullptr,
                               bh ? bh + hstride : nullptr, a.Bp, a.nonfinite);
+        double m_prizu = 0, m_dualzu = 0;
         if (c.active) {
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
-                const int e = c.el(k);
+                const int e = c.gl(k);
                 const float pz = xn[e] - z[k], dz = z[k] - zu[e];
                 m_prizu += (double)pz * pz;
                 m_dualzu += (double)dz * dz;
@@ -392,6 +490,8 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
                 gu[e] = gu[e] + a.rho_u * pz;
             }
         }
+        emit(MGADMM_M_PRI_ZU, m_prizu, true);
+        emit(MGADMM_M_DUAL_ZU, m_dualzu, true);
     }
     // ---- zd solve + gamma_d update (ADMM.py:586-588, 597)
     int itzd = 0;
@@ -401,16 +501,17 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
         for (int k = 0; k < TPG; ++k) {
             z[k] = 0.f;
             if (c.active) {
-                z[k] = zd[c.el(k)];
-                rhs[k] = gd[c.el(k)] / 2.f + a.rho_d / 2.f * xn[c.el(k)];
+                z[k] = zd[c.gl(k)];
+                rhs[k] = gd[c.gl(k)] / 2.f + a.rho_d / 2.f * xn[c.gl(k)];
             }
         }
-        itzd = lds_cg<TPG, 1>(c, br, z, rhs, nullptr, 0, 0, a.rho_d / 2.f, a.mu_d2, a.max_cg, a.cg_tol,
+        itzd = lds_cg<TPG, BAND, 1>(c, br, z, rhs, nullptr, 0, 0, a.rho_d / 2.f, a.mu_d2, a.max_cg, a.cg_tol,
                               ah ? ah + 2 * hstride : nullptr, bh ? bh + 2 * hstride : nullptr, a.Bp, a.nonfinite);
+        double m_prizd = 0, m_dualzd = 0;
         if (c.active) {
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
-                const int e = c.el(k);
+                const int e = c.gl(k);
                 const float pz = xn[e] - z[k], dz = z[k] - zd[e];
                 m_prizd += (double)pz * pz;
                 m_dualzd += (double)dz * dz;
@@ -418,14 +519,21 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
                 gd[e] = gd[e] + a.rho_d * pz;
             }
         }
+        emit(MGADMM_M_PRI_ZD, m_prizd, true);
+        emit(MGADMM_M_DUAL_ZD, m_dualzd, true);
+    } else {
+        emit(MGADMM_M_PRI_ZD, 0.0, false);
+        emit(MGADMM_M_DUAL_ZD, 0.0, false);
     }
 
     // ---- phi prox, gamma update, Ldr/Lu based diagnostics (ADMM.py:600-606, 619, 627-637)
     double m_priphi = 0, m_dualphi = 0, m_dgtv = 0, m_dglr = 0, m_glr = 0;
     __syncthreads();          // every LDS read of the last CG is done
     if (c.active) {
+        float xv[TPG];
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) P[c.el(k)] = xn[c.el(k)];
+        for (int k = 0; k < TPG; ++k) xv[k] = xn[c.gl(k)];
+        c.put(P, xv);
     }
     __syncthreads();
     if (c.active) {
@@ -437,7 +545,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
             m_dgtv += fabs((double)l[k]);
             m_dglr += (double)l[k] * l[k];
             if (a.has_phi) {
-                const int e = c.el(k);
+                const int e = c.gl(k);
                 const float gv = gam[e];
                 const float s = l[k] - gv / a.rho;
                 const float u = fabsf(s) - thr;
@@ -450,24 +558,17 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
             }
         }
         c.op_lu(P, l);
+        float xv[TPG];
+        lds_load<TPG>(P + c.own(), xv);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) m_glr += (double)P[c.el(k)] * (double)l[k];
+        for (int k = 0; k < TPG; ++k) m_glr += (double)xv[k] * (double)l[k];
     }
 
-    // ---- per-sample metric sums (whole-batch values are formed by k_batch_metrics)
-    double vals[MGADMM_NMETRIC];
-    vals[MGADMM_M_XSHIFT] = m_xshift; vals[MGADMM_M_PRI_ZU] = m_prizu; vals[MGADMM_M_DUAL_ZU] = m_dualzu;
-    vals[MGADMM_M_PRI_PHI] = m_priphi; vals[MGADMM_M_DUAL_PHI] = m_dualphi; vals[MGADMM_M_PRI_ZD] = m_prizd;
-    vals[MGADMM_M_DUAL_ZD] = m_dualzd; vals[MGADMM_M_GLR] = m_glr; vals[MGADMM_M_DGTV] = m_dgtv;
-    vals[MGADMM_M_DGLR] = m_dglr; vals[MGADMM_M_RECOVER] = m_rec;
-#pragma unroll
-    for (int m = 0; m < MGADMM_NMETRIC; ++m) {
-        const double s = br.sum(vals[m]);
-        bool keep = true;
-        if ((m == MGADMM_M_PRI_PHI || m == MGADMM_M_DUAL_PHI || m == MGADMM_M_DGTV) && !a.has_phi) keep = false;
-        if ((m == MGADMM_M_PRI_ZD || m == MGADMM_M_DUAL_ZD || m == MGADMM_M_DGLR) && !a.has_zd) keep = false;
-        if (tid == 0) a.ps[(size_t)m * a.Bp + b] = keep ? s : 0.0;
-    }
+    emit(MGADMM_M_PRI_PHI, m_priphi, a.has_phi);
+    emit(MGADMM_M_DUAL_PHI, m_dualphi, a.has_phi);
+    emit(MGADMM_M_DGTV, m_dgtv, a.has_phi);
+    emit(MGADMM_M_DGLR, m_dglr, a.has_zd);
+    emit(MGADMM_M_GLR, m_glr, true);
     if (tid == 0) {
         a.cg_iters[b] = itx;
         a.cg_iters[a.Bp + b] = itzu;
@@ -529,13 +630,24 @@ __global__ __launch_bounds__(256) void k_init_lds(int T, int t_in, int N, int B,
     }
 }
 
-// delta_x_per_step on the sample-major layout: m2[e] = (mean_b (x - x_old)[b][e])^2, then summed per t
+// delta_x_per_step on the sample-major layout.  Pass 1: workgroup (e-block, b-slice) sums x - x_old over
+// its 64 samples -> part[slice][e].  Pass 2: fixed-order sum over the slices, mean, square -> m2[e].
 __global__ __launch_bounds__(256) void k_dxps_sm(int TN, int B, const float* __restrict__ x, const float* __restrict__ xo,
-                                                 double* __restrict__ m2) {
+                                                 double* __restrict__ part) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= TN) return;
+    const int b0 = blockIdx.y * 64, b1 = min(B, b0 + 64);
+    double s = 0.0;
+    for (int b = b0; b < b1; ++b) s += (double)x[(size_t)b * TN + e] - (double)xo[(size_t)b * TN + e];
+    part[(size_t)blockIdx.y * TN + e] = s;
+}
+
+__global__ __launch_bounds__(256) void k_dxps_sm_mean(int TN, int B, int nslices, const double* __restrict__ part,
+                                                      double* __restrict__ m2) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= TN) return;
     double s = 0.0;
-    for (int b = 0; b < B; ++b) s += (double)x[(size_t)b * TN + e] - (double)xo[(size_t)b * TN + e];
+    for (int k = 0; k < nslices; ++k) s += part[(size_t)k * TN + e];
     s /= (double)B;
     m2[e] = s * s;
 }

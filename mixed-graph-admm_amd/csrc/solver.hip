@@ -711,8 +711,9 @@ struct Engine : EngineBase {
         lds.off_en_u = off; off += 2 * nu;
         lds.off_en_d = off; off += 2 * nd;
         lds.off_en_t = off; off += 2 * nt;
+        off += 2;                      // one padding entry: the gather loop reads one entry ahead
         lds.csr_ints = off;
-        lds.lds_bytes = (size_t)12 * T * N + 8 + 32 * sizeof(double) + (size_t)4 * off;
+        lds.lds_bytes = (size_t)12 * T * N + 16 + 32 * sizeof(float) + (size_t)4 * off;
         if (lds.lds_bytes > 160 * 1024) return MGADMM_OK;
         lds.TPG = best;
         lds.G = T / best;
@@ -733,14 +734,18 @@ struct Engine : EngineBase {
         }
         MG_HIP(hipMalloc(&d_lds_csr, sizeof(int) * off));
         MG_HIP(hipMemcpy(d_lds_csr, img.data(), sizeof(int) * off, hipMemcpyHostToDevice));
-        MG_HIP(hipMalloc(&d_m2, sizeof(double) * T * N));
+        MG_HIP(hipMalloc(&d_m2, sizeof(double) * T * N * (1 + (size_t)(Bmax + 63) / 64)));
         lds.ok = true;
         return MGADMM_OK;
     }
 
     template <int TPG>
     int launch_lds(const LdsArgs& a, int B) {
-        auto fn = k_admm_lds<TPG>;
+        return a.band ? launch_lds2<TPG, true>(a, B) : launch_lds2<TPG, false>(a, B);
+    }
+    template <int TPG, bool BAND>
+    int launch_lds2(const LdsArgs& a, int B) {
+        auto fn = k_admm_lds<TPG, BAND>;
         static bool attr_set = false;
         if (!attr_set) {
             MG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -835,8 +840,11 @@ struct Engine : EngineBase {
                     case 12: MG_TRY(launch_lds<12>(a, B)); break;
                     default: mg_set_error("solve_lds: bad TPG"); return MGADMM_ERR_UNSUPPORTED;
                 }
-                hipLaunchKernelGGL(k_dxps_sm, dim3(((int)TN + 255) / 256), dim3(256), 0, st, (int)TN, B, (const float*)xn,
-                                   (const float*)xc, d_m2);
+                const int nsl = (B + 63) / 64;
+                hipLaunchKernelGGL(k_dxps_sm, dim3(((int)TN + 255) / 256, nsl), dim3(256), 0, st, (int)TN, B, (const float*)xn,
+                                   (const float*)xc, d_m2 + TN);
+                hipLaunchKernelGGL(k_dxps_sm_mean, dim3(((int)TN + 255) / 256), dim3(256), 0, st, (int)TN, B, nsl,
+                                   (const double*)(d_m2 + TN), d_m2);
                 hipLaunchKernelGGL(k_dxps_sm_final, dim3(T), dim3(256), 0, st, T, N, (const double*)d_m2, d_dxps + (size_t)it * T);
                 hipLaunchKernelGGL(k_batch_metrics, dim3(MGADMM_NMETRIC), dim3(256), 0, st, (const double*)d_ps, Bp, B,
                                    d_hist + (size_t)it * MGADMM_NMETRIC,
