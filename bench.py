@@ -137,18 +137,36 @@ def load_traffic(workload):
         return None
 
 
-def roofline_from_prof(prof, workload):
+def roofline_from_prof(prof, workload, path="stream", elems=0, cg=None):
+    """Roofline object of the dominant kernel from the live HIP-event timings (tag 0).
+
+    stream path: dominant kernel = the sparse-Laplacian SpMM inside the CG solves; algorithmic bytes are
+                 accumulated per launch by the library (8 B/element per SpMM pass + CSR bytes).
+    lds path   : dominant kernel = k_admm_lds (one launch = one whole ADMM iteration, CG loops inside LDS);
+                 algorithmic bytes per launch follow SURVEY.md 8(d): U * [52 (Kx+1) + 44 (Kzu+1) + 52 (Kzd+1)
+                 + 130] B with the measured mean CG counts.  These bytes never reach HBM on this path, so
+                 `achieved` can exceed the HBM peak; `traffic` is the HBM traffic measured with rocprofv3."""
     p0 = prof[0]
     if p0["count"] == 0 or p0["ms"] <= 0:
         return None
     avg_ms = p0["ms"] / p0["count"]
-    bytes_per = p0["bytes"] / p0["count"]
+    if path == "lds":
+        per_elem = 52 * (cg["CG_iter_x"] + 1) + 44 * (cg["CG_iter_zu"] + 1) + 52 * (cg["CG_iter_zd"] + 1) + 130
+        bytes_per = per_elem * elems
+        kernel = "k_admm_lds<TPG> (LDS-resident fused ADMM iteration: 3 CG solves + prox + duals + history per launch)"
+    else:
+        bytes_per = p0["bytes"] / p0["count"]
+        kernel = "k_rows<SpMM in CG> (sparse mixed-graph Laplacian, batch-innermost)"
     ach = bytes_per / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "k_rows<SpMM in CG> (sparse mixed-graph Laplacian, batch-innermost)",
-            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": load_traffic(workload), "launches": p0["count"], "avg_launch_us": avg_ms * 1e3,
-            "algorithmic_bytes_per_launch": bytes_per,
-            "cg_update_kernel_GBs": (prof[1]["bytes"] / max(prof[1]["ms"], 1e-9) / 1e6) if prof[1]["count"] else None}
+    out = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(workload), "launches": p0["count"],
+           "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": bytes_per}
+    if path == "lds":
+        out["note"] = ("algorithmic bytes (SURVEY 8d) are served from LDS/registers on this path; see `traffic` for the "
+                       "HBM bytes actually moved and `roofline_cfg3` for the HBM-streaming SpMM kernel")
+    else:
+        out["cg_update_kernel_GBs"] = (prof[1]["bytes"] / max(prof[1]["ms"], 1e-9) / 1e6) if prof[1]["count"] else None
+    return out
 
 
 def main():
@@ -212,6 +230,8 @@ def main():
     dt = float(tmax.item())
     cg_counts = {k2: float(torch.stack([v.float().mean() if torch.is_tensor(v) else torch.tensor(float(v))
                                         for v in getattr(blk, k2)]).mean()) for k2 in ("CG_iter_x", "CG_iter_zu", "CG_iter_zd")}
+    from mgadmm import _lib
+    path = "lds" if _lib.lib.mgadmm_solver_path(blk._solvers[(1, torch.float32)][0], B) == _lib.PATH_LDS else "stream"
     finite = bool(torch.isfinite(x).all().item())
 
     out = None
@@ -225,11 +245,11 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": B, "global_batch": world * B,
                        "ablation": "None", "graph": "kNN-directed", "cg_tol": 1e-8, "max_cg_iter": 100,
                        "parallelism": f"batch-sharded x{world}, no collective on the convergence path, final RCCL gather",
-                       "mean_cg_iters": cg_counts, "solver_path": "stream", "all_finite": finite,
+                       "mean_cg_iters": cg_counts, "solver_path": path, "all_finite": finite,
                        "workspace_GB": blk.workspace_bytes() / 1e9, "per_kernel_events_in_timed_region": not args.no_prof},
         }
         if prof:
-            out["roofline"] = roofline_from_prof(prof, args.workload)
+            out["roofline"] = roofline_from_prof(prof, args.workload, path, elems=B * 24 * n, cg=cg_counts)
         else:
             out["roofline"] = None
 

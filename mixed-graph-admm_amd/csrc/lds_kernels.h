@@ -17,7 +17,7 @@
 #include "common.h"
 
 struct LdsArgs {
-    int T, N, TN, t_in, G, B, Bp;
+    int T, N, TN, TS, t_in, G, B, Bp;   // TS: LDS row stride (floats) of a node's time row, >= T
     int nthreads;          // N * G active threads
     int has_phi, has_zd, first;
     int lhsx_kind;         // 1: LHS_x contains cLdr, 0: diagonal ('DGTV'/'UT')
@@ -63,7 +63,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // Fixed-order workgroup sum: per-wave float totals (DPP) -> 16 LDS slots -> every thread adds the 16 slots
-// in double.  `red` holds 2 x 16 floats used alternately, so one barrier per call is enough.
+// in a fixed float tree.  `red` holds 2 x 16 floats used alternately, so one barrier per call is enough.
 struct BlockRed {
     float* red;
     int par;
@@ -75,11 +75,10 @@ struct BlockRed {
         __syncthreads();
         const float4 a = reinterpret_cast<const float4*>(buf)[0], b = reinterpret_cast<const float4*>(buf)[1],
                      c = reinterpret_cast<const float4*>(buf)[2], d = reinterpret_cast<const float4*>(buf)[3];
-        double s = (double)a.x;
-        s += (double)a.y; s += (double)a.z; s += (double)a.w;
-        s += (double)b.x; s += (double)b.y; s += (double)b.z; s += (double)b.w;
-        s += (double)c.x; s += (double)c.y; s += (double)c.z; s += (double)c.w;
-        s += (double)d.x; s += (double)d.y; s += (double)d.z; s += (double)d.w;
+        // fixed association: ((a+b)+(c+d)) component-wise, then (x+y)+(z+w)
+        const float sx = (a.x + b.x) + (c.x + d.x), sy = (a.y + b.y) + (c.y + d.y);
+        const float sz = (a.z + b.z) + (c.z + d.z), sw = (a.w + b.w) + (c.w + d.w);
+        const double s = (double)((sx + sy) + (sz + sw));
         par ^= 1;
         return s;
     }
@@ -121,12 +120,13 @@ __device__ __forceinline__ void lds_store(float* p, const float (&v)[TPG]) {
 }
 
 // Per-thread view: node i, time steps t0 .. t0+TPG-1.
-//   LDS vectors are node-major, time innermost: A[node*T + t]  -> the TPG time steps of any node are one
-//   contiguous, aligned run (vector ds_read), also for a gathered neighbour;
+//   LDS vectors are node-major, time innermost: A[node*TS + t] (row stride TS >= T, an odd number of 16-B
+//   slots so that rows start on all banks) -> the TPG time steps of any node are one contiguous, aligned
+//   run (vector ds_read), also for a gathered neighbour;
 //   HBM state is the reference's (T, N) order per sample: element (t, i) at t*N + i (coalesced over i).
 template <int TPG, bool BAND>
 struct LdsCtx {
-    int T, N, t0, i;
+    int T, TS, N, t0, i;
     bool active;
     float* P;
     float* Q;
@@ -137,7 +137,7 @@ struct LdsCtx {
     const float* band_w;
 
     __device__ __forceinline__ int gl(int k) const { return (t0 + k) * N + i; }   // HBM index
-    __device__ __forceinline__ int own() const { return i * T + t0; }             // LDS index of element k = 0
+    __device__ __forceinline__ int own() const { return i * TS + t0; }            // LDS index of element k = 0
 
     // acc[k] = sum_e w_e * SRC[col_e][t0+k+shift]     (0 outside [0,T))
     __device__ __forceinline__ void gather(const float* SRC, const int2* EN, int e0, int e1, int shift, float (&acc)[TPG]) const {
@@ -148,7 +148,7 @@ struct LdsCtx {
             const int2 en = nx;
             nx = EN[e + 1];
             const float w = __int_as_float(en.y);
-            const float* row = SRC + en.x * T + t0;
+            const float* row = SRC + en.x * TS + t0;
             float v[TPG];
             lds_load<TPG>(row, v);
             if (shift == 0) {
@@ -169,7 +169,7 @@ struct LdsCtx {
     }
     // band (line-graph) stencils on the node's own time row
     __device__ __forceinline__ void band_back(const float* SRC, float (&acc)[TPG]) const {
-        const float* row = SRC + i * T;
+        const float* row = SRC + i * TS;
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
             acc[k] = 0.f;
@@ -182,7 +182,7 @@ struct LdsCtx {
         }
     }
     __device__ __forceinline__ void band_fwd(const float* SRC, float (&acc)[TPG]) const {
-        const float* row = SRC + i * T;
+        const float* row = SRC + i * TS;
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
             acc[k] = 0.f;
@@ -344,9 +344,10 @@ template <int TPG, bool BAND>
 __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     float* P = reinterpret_cast<float*>(lds_raw);
-    float* Q = P + a.TN;
-    float* AP = Q + a.TN;
-    float* red = AP + a.TN + ((4 - (a.TN & 3)) & 3);                   // 16-byte aligned, 2 x 16 floats
+    const int LN = a.N * a.TS;                                         // floats per LDS vector (TS % 4 == 0 or TS == T)
+    float* Q = P + LN;
+    float* AP = Q + LN;
+    float* red = AP + LN + ((4 - (LN & 3)) & 3);                       // 16-byte aligned, 2 x 16 floats
     int* csr = reinterpret_cast<int*>(red + 32);
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
     if (tid < 32) red[tid] = 0.f;          // slots of non-existent waves must read as 0
 
     LdsCtx<TPG, BAND> c;
-    c.T = a.T; c.N = a.N;
+    c.T = a.T; c.TS = a.TS; c.N = a.N;
     c.active = tid < a.nthreads;
     const int g = c.active ? tid / a.N : 0;
     c.i = c.active ? tid - g * a.N : 0;

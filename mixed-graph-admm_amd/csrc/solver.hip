@@ -60,7 +60,7 @@ struct Engine : EngineBase {
     // LDS-resident fused path (float32, small graphs)
     struct LdsPlan {
         bool ok = false;
-        int G = 0, TPG = 0, nthreads = 0, block = 0, csr_ints = 0;
+        int G = 0, TPG = 0, TS = 0, nthreads = 0, block = 0, csr_ints = 0;
         int off_rp_u = 0, off_rp_d = 0, off_rp_t = 0, off_en_u = 0, off_en_d = 0, off_en_t = 0;
         size_t lds_bytes = 0;
     } lds;
@@ -713,7 +713,14 @@ struct Engine : EngineBase {
         lds.off_en_t = off; off += 2 * nt;
         off += 2;                      // one padding entry: the gather loop reads one entry ahead
         lds.csr_ints = off;
-        lds.lds_bytes = (size_t)12 * T * N + 16 + 32 * sizeof(float) + (size_t)4 * off;
+        // LDS row stride: T padded to an odd number of 16-byte slots (rows then start on every bank group);
+        // fall back to the unpadded stride when the padded vectors do not fit
+        int ts = (T + 3) / 4 * 4;
+        if (((ts / 4) & 1) == 0) ts += 4;
+        auto bytes_for = [&](int stride) { return (size_t)12 * N * stride + 16 + 32 * sizeof(float) + (size_t)4 * off; };
+        if (bytes_for(ts) > 160 * 1024) ts = T;
+        lds.TS = ts;
+        lds.lds_bytes = bytes_for(ts);
         if (lds.lds_bytes > 160 * 1024) return MGADMM_OK;
         lds.TPG = best;
         lds.G = T / best;
@@ -799,7 +806,7 @@ struct Engine : EngineBase {
                 MG_HIP(hipGetLastError());
             }
             LdsArgs a{};
-            a.T = T; a.N = N; a.TN = (int)TN; a.t_in = p.t_in; a.G = lds.G; a.B = B; a.Bp = Bp;
+            a.T = T; a.N = N; a.TN = (int)TN; a.TS = lds.TS; a.t_in = p.t_in; a.G = lds.G; a.B = B; a.Bp = Bp;
             a.nthreads = lds.nthreads;
             a.has_phi = has_phi; a.has_zd = has_zd;
             const LhsDef dx = lhs_def(MGADMM_LHS_X);
