@@ -86,7 +86,7 @@ typedef struct {
     int32_t q1_identity_t0;       /* 1: reproduce ADMM.py:221-222 (Ldr_T keeps +I on the t=0 block) */
     int32_t skip;                 /* BAND mode: skip_connection */
     const float* band_w;          /* BAND mode: T*skip weights, row t = weights of x[t-1-s] (ADMM.py:43-49) */
-    int32_t reorder;              /* 0: keep node order; 1: bandwidth-reducing (RCM) internal order */
+    int32_t reorder;              /* internal node order: 0 keep, 1 RCM (bandwidth), 2 greedy cluster growth (locality for LDS tiles) */
     int32_t device;               /* HIP device ordinal */
 } mgadmm_graph_desc;
 

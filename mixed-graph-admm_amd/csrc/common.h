@@ -67,6 +67,7 @@ struct mgadmm_graph {
     int N = 0, T = 0, mode = 0, device = 0;
     int transpose_by_gather = 0, q1 = 0, skip = 0;
     bool has_perm = false;
+    int reorder = 0;              // 0 none, 1 RCM, 2 greedy cluster order (enables the LDS-tiled row kernel)
     HostCsr hWu, hWd, hWdT;       // API node order (hWdT: exact transpose, or hWd when transpose_by_gather)
     std::vector<int> perm, iperm;  // perm[i] = API node at internal row i; iperm = inverse
     DevCsr Wu, Wd, WdT;            // internal node order, device
@@ -82,6 +83,7 @@ struct mgadmm_graph {
 // graph.hip
 int mg_transpose_csr(const HostCsr& A, HostCsr& At);
 int mg_rcm_order(const HostCsr& A, const HostCsr* B, std::vector<int>& perm);
+int mg_cluster_order(const HostCsr& A, const HostCsr* B, int csize, std::vector<int>& perm);
 int mg_permute_csr(const HostCsr& A, const std::vector<int>& perm, const std::vector<int>& iperm, HostCsr& out);
 
 struct EngineBase;

@@ -56,6 +56,11 @@ struct Engine : EngineBase {
     int* h_flag = nullptr;
     hipEvent_t ev_ring[LAG + 1] = {nullptr};
     int want_blocks = 2048;
+    struct TileMetaDev { int R = 0; int* tl_col = nullptr; float* tl_w = nullptr; int* halo = nullptr; int* h_rowptr = nullptr; int* h_col = nullptr; float* h_val = nullptr; };
+    TileMetaDev tmeta[3];         // W_u, W_d, W_d^T metadata for the tile size in use
+    int cur_P = 0;                // partial rows written by the last row-kernel launch (k_rows or k_tile)
+    int use_tile = 0;             // experimental LDS-tiled spatial kernel on cluster-ordered graphs (MGADMM_TILE=1 enables):
+                                  // parity-tested, but slower than k_rows in round 1
     int64_t ws_bytes = 0;
     // LDS-resident fused path (float32, small graphs)
     struct LdsPlan {
@@ -82,6 +87,7 @@ struct Engine : EngineBase {
         fr(vec_pool); fr(partials); fr(d_rr); fr(d_alpha); fr(d_beta); fr(d_alpha_hist); fr(d_beta_hist);
         fr(d_active); fr(d_iters_tmp); fr(d_nact); fr(d_nonfinite); fr(d_ps); fr(d_hist); fr(d_dxps);
         fr(d_dxpart); fr(d_hist_ps); fr(d_cg_iters); fr(d_lds_csr); fr(d_m2);
+        for (auto& tmd : tmeta) { fr(tmd.tl_col); fr(tmd.tl_w); fr(tmd.halo); fr(tmd.h_rowptr); fr(tmd.h_col); fr(tmd.h_val); }
         if (h_nact) (void)hipHostFree(h_nact);
         if (h_row) (void)hipHostFree(h_row);
         if (h_flag) (void)hipHostFree(h_flag);
@@ -110,14 +116,116 @@ struct Engine : EngineBase {
         int ri = 16;
         while (ri > 4 && rows / ri < 2L * q.P) ri -= 4;
         q.RI = ri;
-        q.NBLK = (N + ri - 1) / ri;
-        q.n_items = T * q.NBLK;
+        const int per_xcd = (N + 7) / 8;
+        q.NBL = (per_xcd + ri - 1) / ri;
+        q.NX = q.NBL * ri;
+        q.n_items = T * q.NBL;
         q.grid = q.P * q.CH;
         return q;
     }
 
+    // geometry of the LDS-tiled spatial kernel for the same column layout as `q`
+    bool make_tile_geom(const Geom& q, TileGeom& tg) const {
+        if (!use_tile || g->reorder < 2 || g->mode != MGADMM_TEMPORAL_SPATIAL) return false;
+        tg.T = T; tg.N = N; tg.B = q.B; tg.Bp = q.Bp; tg.VEC = q.VEC; tg.CH = q.CH;
+        // largest R <= 40 (multiple of 4) that still yields >= 512 workgroups, then the best-balanced R nearby
+        const int rmax = 4 * TILE_MAXR;
+        int best = 0;
+        double best_score = -1;
+        for (int R = 8; R <= rmax; R += 4) {
+            const long blocks = (long)q.CH * ((N + R - 1) / R);
+            const long rounds = (blocks + 511) / 512;                  // 2 resident workgroups per CU
+            const double fill = (double)blocks / (double)(rounds * 512);
+            const double score = fill * (0.5 + 0.5 * R / rmax);      // prefer full machines and large tiles
+            if (score > best_score) { best_score = score; best = R; }
+        }
+        if (const char* e = getenv("MGADMM_TILE_R")) { int rr = atoi(e); if (rr >= 4 && rr <= rmax && rr % 4 == 0) best = rr; }
+        tg.R = best;
+        tg.NTILE = (N + best - 1) / best;
+        tg.TPX = (tg.NTILE + 7) / 8;
+        tg.P = 8 * tg.TPX;
+        tg.grid = tg.P * q.CH;
+        const size_t row_bytes = (size_t)64 * q.VEC * sizeof(S);
+        tg.lds_bytes = (int)std::max(row_bytes * (best + TILE_HMAX), (size_t)3 * q.VEC * 64 * sizeof(S));
+        return true;
+    }
+
+    // host-side preprocessing of one CSR matrix for tile size R (see TileMeta in stream_kernels.h)
+    int tile_meta(int which, int R, TileMeta& out) {
+        TileMetaDev& d = tmeta[which];
+        if (d.R != R) {
+            const HostCsr& src = which == 0 ? g->hWu : (which == 1 ? g->hWd : g->hWdT);
+            HostCsr A;
+            if (g->has_perm) mg_permute_csr(src, g->perm, g->iperm, A);
+            else A = src;
+            const int ntile = (N + R - 1) / R;
+            std::vector<int> tc((size_t)N * TILE_GW), hr(N + 1, 0), hcol, halo((size_t)ntile * TILE_HMAX, -1);
+            std::vector<float> tw((size_t)N * TILE_GW, 0.f), hval;
+            for (int tl = 0; tl < ntile; ++tl) {
+                const int lo = tl * R, hi = std::min(N, lo + R);
+                // halo list of the tile: out-of-tile columns in order of first use, at most TILE_HMAX
+                std::vector<int> hl;
+                auto halo_pos = [&](int c) -> int {
+                    for (size_t k = 0; k < hl.size(); ++k)
+                        if (hl[k] == c) return (int)k;
+                    if ((int)hl.size() < TILE_HMAX) { hl.push_back(c); return (int)hl.size() - 1; }
+                    return -1;
+                };
+                for (int i = lo; i < hi; ++i) {
+                    int used = 0;
+                    for (int e = A.rowptr[i]; e < A.rowptr[i + 1]; ++e) {
+                        const int c = A.col[e];
+                        int local = -1;
+                        if (used < TILE_GW) {
+                            if (c >= lo && c < hi) local = c - lo;
+                            else {
+                                const int hp = halo_pos(c);
+                                if (hp >= 0) local = R + hp;
+                            }
+                        }
+                        if (local >= 0) {
+                            tc[(size_t)i * TILE_GW + used] = local;
+                            tw[(size_t)i * TILE_GW + used] = A.val[e];
+                            ++used;
+                        } else {
+                            hcol.push_back(c);
+                            hval.push_back(A.val[e]);
+                        }
+                    }
+                    for (; used < TILE_GW; ++used) tc[(size_t)i * TILE_GW + used] = i - lo;
+                    hr[i + 1] = (int)hcol.size();
+                }
+                for (size_t k = 0; k < hl.size(); ++k) halo[(size_t)tl * TILE_HMAX + k] = hl[k];
+            }
+            MG_HIP(hipStreamSynchronize(st));
+            auto fr = [](void* q) { if (q) (void)hipFree(q); };
+            fr(d.tl_col); fr(d.tl_w); fr(d.halo); fr(d.h_rowptr); fr(d.h_col); fr(d.h_val);
+            d = TileMetaDev();
+            const size_t nh = hcol.size() + 8;
+            hcol.resize(nh, 0);
+            hval.resize(nh, 0.f);
+            MG_HIP(hipMalloc(&d.tl_col, tc.size() * sizeof(int)));
+            MG_HIP(hipMalloc(&d.tl_w, tw.size() * sizeof(float)));
+            MG_HIP(hipMalloc(&d.halo, halo.size() * sizeof(int)));
+            MG_HIP(hipMemcpy(d.halo, halo.data(), halo.size() * sizeof(int), hipMemcpyHostToDevice));
+            MG_HIP(hipMalloc(&d.h_rowptr, hr.size() * sizeof(int)));
+            MG_HIP(hipMalloc(&d.h_col, nh * sizeof(int)));
+            MG_HIP(hipMalloc(&d.h_val, nh * sizeof(float)));
+            MG_HIP(hipMemcpy(d.tl_col, tc.data(), tc.size() * sizeof(int), hipMemcpyHostToDevice));
+            MG_HIP(hipMemcpy(d.tl_w, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+            MG_HIP(hipMemcpy(d.h_rowptr, hr.data(), hr.size() * sizeof(int), hipMemcpyHostToDevice));
+            MG_HIP(hipMemcpy(d.h_col, hcol.data(), nh * sizeof(int), hipMemcpyHostToDevice));
+            MG_HIP(hipMemcpy(d.h_val, hval.data(), nh * sizeof(float), hipMemcpyHostToDevice));
+            d.R = R;
+        }
+        out.tl_col = d.tl_col; out.tl_w = d.tl_w; out.halo = d.halo; out.h_rowptr = d.h_rowptr; out.h_col = d.h_col; out.h_val = d.h_val;
+        return MGADMM_OK;
+    }
+
     int ensure_partials(const Geom& q) {
-        size_t need = (size_t)NRED_MAX * q.P * q.Bp;
+        TileGeom tg;
+        const int pmax = make_tile_geom(q, tg) ? std::max(q.P, tg.P) : q.P;
+        size_t need = (size_t)NRED_MAX * pmax * q.Bp;
         if (need <= partials_elems) return MGADMM_OK;
         MG_HIP(hipStreamSynchronize(st));
         if (partials) MG_HIP(hipFree(partials));
@@ -131,6 +239,7 @@ struct Engine : EngineBase {
     int init() override {
         MG_HIP(hipSetDevice(g->device));
         if (const char* e = getenv("MGADMM_WANT_BLOCKS")) want_blocks = std::max(64, atoi(e));
+        if (const char* e = getenv("MGADMM_TILE")) use_tile = atoi(e);
         Geom q = make_geom(Bmax);
         Bp_max = q.Bp;
         // Bp for smaller batches never exceeds Bp_max rounded to 256
@@ -255,8 +364,25 @@ struct Engine : EngineBase {
     template <int VEC, int GW, class Epi>
     int rows_v(const Geom& q, const OpDesc& op, const S* in, const Epi& epi, const int* live, int tag, double bytes) {
         const bool timed = prof_open(tag, bytes);
-        hipLaunchKernelGGL((k_rows<S, VEC, Epi, GW>), dim3(q.grid), dim3(256), 0, st, q, op, op.rowptr, op.col, op.val,
-                           op.band_w, in, epi, partials, live);
+        TileGeom tg;
+        if (op.kind == OPK_SPATIAL && make_tile_geom(q, tg)) {
+            const int which = op.rowptr == g->Wu.rowptr ? 0 : (op.rowptr == g->Wd.rowptr ? 1 : 2);
+            TileMeta tmv;
+            MG_TRY(tile_meta(which, tg.R, tmv));
+            auto fn = k_tile<S, VEC, Epi>;
+            static bool attr_set = false;
+            if (!attr_set) {
+                MG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(fn, dim3(tg.grid), dim3(256), tg.lds_bytes, st, tg, op, tmv.tl_col, tmv.tl_w, tmv.halo, tmv.h_rowptr,
+                               tmv.h_col, tmv.h_val, in, epi, partials, live);
+            cur_P = tg.P;
+        } else {
+            hipLaunchKernelGGL((k_rows<S, VEC, Epi, GW>), dim3(q.grid), dim3(256), 0, st, q, op, op.rowptr, op.col, op.val,
+                               op.band_w, in, epi, partials, live);
+            cur_P = q.P;
+        }
         if (timed) prof_close();
         MG_HIP(hipGetLastError());
         return MGADMM_OK;
@@ -292,7 +418,7 @@ struct Engine : EngineBase {
     template <int NRED, class Fin>
     int reduce(const Geom& q, const Fin& fin, const int* live) {
         prof_open(3, 0);
-        hipLaunchKernelGGL((k_reduce<S, NRED, Fin>), dim3(q.Bp / 64), dim3(1024), 0, st, partials, q.P, q.Bp, fin, live);
+        hipLaunchKernelGGL((k_reduce<S, NRED, Fin>), dim3(q.Bp / 64), dim3(1024), 0, st, partials, cur_P, q.Bp, fin, live);
         MG_HIP(hipGetLastError());
         return MGADMM_OK;
     }

@@ -32,8 +32,9 @@ __device__ __forceinline__ void stv(S* p, const Vec<S, V>& x) {
 struct Geom {
     int T, N, B, Bp;
     int VEC, CH;         // columns per lane; column chunks of 64*VEC
-    int RI, NBLK;        // rows per work item; items per time slice = ceil(N / RI)
-    int n_items;         // T * NBLK work items per column chunk, enumerated t-major
+    int RI;              // rows per work item
+    int NX, NBL;         // node rows owned by one XCD (multiple of RI); work items per time slice and XCD
+    int n_items;         // T * NBL work items per (XCD, column chunk), enumerated t-major
     int G8;              // workgroups per (XCD, column chunk)
     int P;               // partial-sum rows per column = 8 * G8 (one per workgroup of a chunk)
     int grid;            // 8 * G8 * CH workgroups
@@ -113,13 +114,13 @@ __device__ __forceinline__ void row_entries(const int* __restrict__ colidx, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row kernel.  Work item = RI consecutive node rows of one time slice; items are enumerated t-major
-// (all node blocks of slice 0, then slice 1, ...).  The grid is persistent-sized (8*G8 workgroups per
-// column chunk): in round k the whole chunk group works on items [k*P, (k+1)*P) and XCD x on the
-// contiguous eighth [k*P + x*G8, +G8) of them.  So (a) every XCD sweeps contiguous node ranges (the
-// neighbour rows of a spatial gather are rows its own L2 has just fetched), and (b) the whole device
-// moves through time slices together, so the rows a time-shifted operator (Ldr / Ldr^T) gathers from
-// slice t -/+ 1 were streamed a few tens of MB ago and are still in the 256 MiB Infinity Cache.
+// Row kernel.  Work item = RI consecutive node rows of one time slice.  The grid is persistent-sized
+// (8*G8 workgroups per column chunk).  XCD x (= blockIdx & 7, the round-robin dispatch group) owns the
+// SAME contiguous node range [x*NX, (x+1)*NX) in every time slice, and its G8 workgroups sweep the items of
+// that range t-major (all node blocks of slice 0, then slice 1, ...).  So (a) the neighbour rows of a
+// spatial gather are rows this XCD's own L2 has just fetched, and (b) the rows a time-shifted operator
+// (Ldr / Ldr^T) gathers from slice t -/+ 1 are rows the same XCD streamed one local slice (NX rows) earlier:
+// they are served by its 4 MiB L2 (or the Infinity Cache) instead of being fetched from HBM a second time.
 // Each wave owns rows (wave, wave+4, ...) of an item over 64*VEC batch columns; CSR metadata of the
 // next row is prefetched through the scalar cache while the gathers of the current row are in flight.
 // partials: [NRED][P][Bp] per-workgroup per-column partial sums (summed by k_reduce in fixed order).
@@ -151,11 +152,12 @@ __global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __re
         for (int v = 0; v < VEC; ++v) acc[rr][v] = S(0);
 
     const bool spatial = op.kind == OPK_SPATIAL;
-    for (int item = slot; item < g.n_items; item += g.P) {
-        const int t = item / g.NBLK;
-        const int nb = item - t * g.NBLK;
-        const int n0 = nb * g.RI;
-        const int n1 = min(g.N, n0 + g.RI);
+    const int xlo = xcd * g.NX, xhi = min(g.N, xlo + g.NX);   // node rows this XCD owns, for every time slice
+    for (int item = r; item < g.n_items; item += g.G8) {
+        const int t = item / g.NBL;
+        const int nb = item - t * g.NBL;
+        const int n0 = xlo + nb * g.RI;
+        const int n1 = min(xhi, n0 + g.RI);
         int i = n0 + wave;
         if (i >= n1) continue;
         if (spatial) {
@@ -221,6 +223,204 @@ __global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __re
 
     if (Epi::NRED > 0) {
         __shared__ S sm[3][VEC][64];
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            if (wave > 0) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) sm[wave - 1][v][lane] = acc[rr][v];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                Vec<S, VEC> o;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) o.v[v] = ((acc[rr][v] + sm[0][v][lane]) + sm[1][v][lane]) + sm[2][v][lane];
+                stv<S, VEC>(partials + ((size_t)rr * g.P + slot) * g.Bp + col0, o);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-tiled row kernel for the spatial operators (Lu, Ldr, Ldr^T) on a cluster-ordered graph.
+//
+// A workgroup owns a TILE of R consecutive node rows (a graph cluster after mg_cluster_order) of one
+// column chunk and sweeps the T time slices in order (ascending for shift <= 0, descending for Ldr^T).
+// The tile's rows of the slice the gathers read (t + shift: the slice the workgroup streamed in its
+// previous step, or the current one for Lu) are kept in LDS, so an in-tile neighbour costs one
+// conflict-free ds_read_b128 instead of a trip through L1/L2, and every slice is fetched from HBM once
+// instead of twice (once as "own" rows, once as gathered rows).  Out-of-tile neighbours (the halo, ~10-15 %
+// of the entries under the cluster order) are read from global memory; consecutive tiles run on the same
+// XCD, so the halo usually hits that XCD's L2.  Own rows of a step are loaded up front (MAXR x 1 KiB per
+// wave in flight), the epilogue functors are the ones of k_rows.
+// ---------------------------------------------------------------------------------------------
+struct TileGeom {
+    int T, N, B, Bp;
+    int VEC, CH;
+    int R;        // node rows per tile (<= 4 * TILE_MAXR)
+    int NTILE;    // tiles per column chunk
+    int TPX;      // tile slots per XCD = ceil(NTILE / 8)
+    int P;        // partial rows per column = 8 * TPX
+    int grid;     // 8 * TPX * CH workgroups
+    int lds_bytes;
+};
+constexpr int TILE_MAXR = 10;   // rows per wave and time step (4 waves -> R <= 40)
+constexpr int TILE_GW = 6;      // neighbour slots per row held in VGPR lanes (TILE_MAXR*TILE_GW <= 64)
+constexpr int TILE_HMAX = 24;   // halo rows (out-of-tile neighbours) staged in LDS per tile and step
+constexpr int TILE_HPW = TILE_HMAX / 4;   // halo rows loaded by one wave
+
+// Per-(matrix, R) metadata built on the host (Engine::tile_meta):
+//   tl_col/tl_w [N][TILE_GW] : the row's first TILE_GW "local" neighbours and weights.  Local index
+//                              0..R-1 = row of the own tile, R..R+H-1 = position in the tile's halo list;
+//                              unused slots point at the row itself with weight 0
+//   halo [NTILE][TILE_HMAX]  : global row indices of the tile's halo rows (-1 = unused)
+//   h_rowptr/h_col/h_val     : CSR of everything that did not fit (more than TILE_GW neighbours, more than
+//                              TILE_HMAX halo rows): gathered from global memory, normally empty
+struct TileMeta {
+    const int* tl_col;
+    const float* tl_w;
+    const int* halo;
+    const int* h_rowptr;
+    const int* h_col;
+    const float* h_val;
+};
+
+template <typename S, int VEC, class Epi>
+__global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* __restrict__ tl_col,
+                                              const float* __restrict__ tl_w, const int* __restrict__ halo,
+                                              const int* __restrict__ h_rowptr, const int* __restrict__ h_col,
+                                              const float* __restrict__ h_val, const S* __restrict__ in, Epi epi_in,
+                                              S* __restrict__ partials, const int* __restrict__ live) {
+    extern __shared__ __align__(16) unsigned char tile_raw[];
+    if (live != nullptr && *live == 0) return;
+    constexpr int W = 64 * VEC;
+    S* tile = reinterpret_cast<S*>(tile_raw);          // [R + TILE_HMAX][W]: own-tile rows, then halo rows
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xcd = blockIdx.x & 7;
+    const int q = blockIdx.x >> 3;
+    const int chunk = q % g.CH;
+    const int r = q / g.CH;
+    const int tidx = xcd * g.TPX + r;                  // consecutive tiles share an XCD (halo rows hit its L2)
+    const int col0 = (chunk * 64 + lane) * VEC;
+    const int n0 = tidx * g.R;
+    const int n1 = (tidx < g.NTILE) ? min(g.N, n0 + g.R) : n0;
+    const int m = (n1 - n0 - wave + 3) / 4;            // rows of this wave: n0 + wave + 4*j, j < m
+
+    // wave-resident metadata: lane (j*TILE_GW + u) holds slot u of row j; lane j also holds the overflow
+    // bounds of row j; lane k < TILE_HPW holds the global index of halo row (wave + 4*k) of this tile
+    int mcol = 0, mw = 0, hs = 0, hc = 0, hrow = -1;
+    {
+        const int j = lane / TILE_GW, u = lane - j * TILE_GW;
+        if (j < m && j < TILE_MAXR) {
+            const int i = n0 + wave + 4 * j;
+            mcol = tl_col[(size_t)i * TILE_GW + u];
+            mw = __float_as_int(tl_w[(size_t)i * TILE_GW + u]);
+        }
+        if (lane < m) {
+            const int i = n0 + wave + 4 * lane;
+            hs = h_rowptr[i];
+            hc = h_rowptr[i + 1] - hs;
+        }
+        if (lane < TILE_HPW && tidx < g.NTILE) hrow = halo[(size_t)tidx * TILE_HMAX + wave + 4 * lane];
+    }
+
+    Epi epi = epi_in;
+    epi.begin(col0);
+    constexpr int NR = Epi::NRED > 0 ? Epi::NRED : 1;
+    S acc[NR][VEC];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[rr][v] = S(0);
+
+    const int shift = op.shift;
+    const S* trow = tile + lane * VEC;
+    S* hdst = tile + (size_t)g.R * W + lane * VEC;
+    for (int step = 0; step < g.T; ++step) {
+        const int t = shift > 0 ? g.T - 1 - step : step;
+        const int ts = t + shift;
+        const bool tvalid = ts >= 0 && ts < g.T;
+        S selfc = S(1);
+        if (op.self_mode == SELF_LDR) selfc = (t >= 1) ? S(1) : S(0);
+        else if (op.self_mode == SELF_LDRT) selfc = (t > 0 || op.q1) ? S(1) : S(0);
+        const S* obase = in + (size_t)t * g.N * g.Bp + col0;
+        const S* gbase = in + (size_t)(tvalid ? ts : t) * g.N * g.Bp + col0;
+        // 1. own rows of this step and the halo rows of the gathered slice, all in flight together
+        Vec<S, VEC> own[TILE_MAXR];
+#pragma unroll
+        for (int j = 0; j < TILE_MAXR; ++j)
+            if (j < m) own[j] = ldv<S, VEC>(obase + (size_t)(n0 + wave + 4 * j) * g.Bp);
+        if (tvalid) {
+            Vec<S, VEC> hv[TILE_HPW];
+#pragma unroll
+            for (int k = 0; k < TILE_HPW; ++k) {
+                const int hr = __builtin_amdgcn_readlane(hrow, k);
+                if (hr >= 0) hv[k] = ldv<S, VEC>(gbase + (size_t)hr * g.Bp);
+            }
+#pragma unroll
+            for (int k = 0; k < TILE_HPW; ++k) {
+                const int hr = __builtin_amdgcn_readlane(hrow, k);
+                if (hr >= 0) stv<S, VEC>(hdst + (size_t)(wave + 4 * k) * W, hv[k]);
+            }
+        }
+        if (shift == 0) {                               // Lu gathers from the slice it is loading
+#pragma unroll
+            for (int j = 0; j < TILE_MAXR; ++j)
+                if (j < m) stv<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
+        }
+        __syncthreads();                                // halo (and for Lu the own rows) visible
+        // 2. gathers + epilogue, row by row: every regular neighbour is a conflict-free LDS row read
+#pragma unroll
+        for (int j = 0; j < TILE_MAXR; ++j) {
+            if (j < m) {
+                const int i = n0 + wave + 4 * j;
+                Vec<S, VEC> sum;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) sum.v[v] = S(0);
+                if (tvalid) {
+                    Vec<S, VEC> nv[TILE_GW];
+#pragma unroll
+                    for (int u = 0; u < TILE_GW; ++u) {
+                        const int lc = __builtin_amdgcn_readlane(mcol, j * TILE_GW + u);
+                        nv[u] = ldv<S, VEC>(trow + (size_t)lc * W);
+                    }
+#pragma unroll
+                    for (int u = 0; u < TILE_GW; ++u) {
+                        const S w = (S)__int_as_float(__builtin_amdgcn_readlane(mw, j * TILE_GW + u));
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) sum.v[v] += w * nv[u].v[v];
+                    }
+                    const int hcount = __builtin_amdgcn_readlane(hc, j);   // overflow entries (normally 0)
+                    if (hcount > 0) {
+                        const int hstart = __builtin_amdgcn_readlane(hs, j);
+                        for (int e = hstart; e < hstart + hcount; ++e) {
+                            const Vec<S, VEC> x = ldv<S, VEC>(gbase + (size_t)h_col[e] * g.Bp);
+                            const S w = (S)h_val[e];
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) sum.v[v] += w * x.v[v];
+                        }
+                    }
+                }
+                Vec<S, VEC> l;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) l.v[v] = selfc * own[j].v[v] - sum.v[v];
+                epi.row(t, ((size_t)t * g.N + i) * g.Bp + col0, own[j], l, acc);
+            }
+        }
+        __syncthreads();                                // every gather of this step is done
+        // 3. this step's rows become the gathered slice of the next step
+        if (shift != 0) {
+#pragma unroll
+            for (int j = 0; j < TILE_MAXR; ++j)
+                if (j < m) stv<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
+        }
+    }
+
+    if (Epi::NRED > 0) {
+        __syncthreads();                                            // last step's tile stores are done
+        S(*sm)[VEC][64] = reinterpret_cast<S(*)[VEC][64]>(tile);   // the tile is dead now: reuse it
+        const int slot = tidx;
 #pragma unroll
         for (int rr = 0; rr < NR; ++rr) {
             if (wave > 0) {

@@ -53,7 +53,8 @@ class ADMM_algorithm():
       bug_compat      reproduce the reference's quirk Q1 (Ldr_T keeps the identity on the t=0 block,
                       ADMM.py:221-222); default True so iterates match the reference
       tables          optional (connect_list, dist_list) to skip neighbour search (large graphs)
-      reorder         internal bandwidth-reducing node order: True/False/'auto' (N >= 2048)
+      reorder         internal node order: False/0, 'rcm'/1, 'cluster'/2 (greedy cluster growth; enables the
+                      LDS-tiled SpMM kernel) or 'auto' (cluster order for N >= 1024)
       record_cg_coeffs  keep alpha/beta of every CG iteration: True/False/'auto' (B <= 64)
     """
 
@@ -177,7 +178,8 @@ class ADMM_algorithm():
         N = self.n_nodes * Cn
         reorder = self.reorder
         if reorder == 'auto':
-            reorder = N >= 2048
+            reorder = 2 if N >= 1024 else 0          # greedy cluster order (see csrc/graph.hip) for large graphs
+        reorder = {'rcm': 1, 'cluster': 2}[reorder] if isinstance(reorder, str) else int(reorder)
         dev = self.device
         if self.use_line_graph:
             bw = self.d_ew[:, :, 0].contiguous().cpu().numpy()

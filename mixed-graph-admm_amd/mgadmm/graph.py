@@ -78,7 +78,7 @@ class Graph:
             d.band_w = _ptr(bw, C.c_float)
         d.transpose_by_gather = int(bool(transpose_by_gather))
         d.q1_identity_t0 = int(bool(q1_identity_t0))
-        d.reorder = int(bool(reorder))
+        d.reorder = int(reorder)             # 0 none, 1 RCM, 2 greedy cluster order
         d.device = self.device
         h = C.c_void_p()
         _lib.check(_lib.lib.mgadmm_graph_create(C.byref(d), C.byref(h)))

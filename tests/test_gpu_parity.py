@@ -68,15 +68,17 @@ def test_operators_match_reference_dense(mode, dt):
 
 
 @pytest.mark.parametrize("B", [1, 3, 100, 200, 260])
-def test_operators_all_vector_widths_and_reorder(B):
+def test_operators_all_vector_widths_and_reorder(B, monkeypatch):
     """B = 1..260 walks the VEC=1/2/4 kernels and ragged column padding; reorder=True exercises the
     internal node permutation.  Checked against the oracle on random data."""
     meta = load_golden("g4_meta.npz")
     rng = np.random.default_rng(B)
     x = rng.standard_normal((B, 24, 30, 1))
+    if B in (3, 260):
+        monkeypatch.setenv("MGADMM_TILE", "1")          # "cluster" order + the experimental LDS-tiled kernel
     for mode in ("knn", "skip3"):
         o = make_oracle(meta, mode)
-        for reorder in (False, True):
+        for reorder in (False, "rcm", "cluster"):          # "cluster" also switches the spatial ops to the LDS-tiled kernel
             blk = make_product(meta, mode, compute_dtype=torch.float64, reorder=reorder)
             for nm in ("Lu", "Ldr", "Ldr_T", "cLdr"):
                 got = getattr(blk, "apply_op_" + nm)(T_(x))
@@ -444,3 +446,37 @@ def test_lds_path_selection_and_cg_coefficients():
     with pytest.raises(_lib.MgadmmError):
         blk.combined_loop(torch.from_numpy(y), print_info=False)
     blk.close()
+
+
+@pytest.mark.parametrize("dt,xtol,htol,slack", [(torch.float64, 1e-10, 1e-8, 0), (torch.float32, 1e-5, 1e-3, 1)])
+def test_tiled_kernel_full_solves(g4_meta, g4_solves, dt, xtol, htol, slack, monkeypatch):
+    """Streaming path on a cluster-ordered graph with the experimental LDS-tiled spatial kernel (k_tile,
+    MGADMM_TILE=1) and the node permutation applied at the ABI.  Same golden solves, same tolerances."""
+    monkeypatch.setenv("MGADMM_TILE", "1")
+    n = 0
+    for key in all_keys(g4_solves, "f64"):
+        mode, abl, task, tag, iters = key.split("-")
+        if mode not in ("knn", "physical") or int(iters) != 5:
+            continue
+        y, mask = case_inputs(g4_meta, task, np.float64)
+        blk = make_product(g4_meta, mode, ablation=abl, compute_dtype=dt, path="stream", reorder="cluster")
+        blk.max_ADMM_iter = 5
+        x, (zu, zd), phi, hist = blk.solve(torch.from_numpy(y), mask=torch.from_numpy(mask) if mask is not None else None)
+        G = lambda f: g4_solves[f"{key}/{f}"]
+        check_solve(blk, key, G, abl, x, xtol, htol, slack)
+        assert rel(zu, G("zu")) < xtol * 10
+        perm = blk._graphs[1][0].perm()
+        assert sorted(perm.tolist()) == list(range(30)) and perm.tolist() != list(range(30))
+        blk.close()
+        n += 1
+    assert n >= 9
+    # batched, ragged column padding, VEC=4 chunks
+    g = load_golden("g5_batched.npz")
+    y = np.concatenate([g["y"]] * 33, 0)[:260]
+    a = make_product(g4_meta, "knn", compute_dtype=dt, path="stream", reorder="cluster")
+    b = make_product(g4_meta, "knn", compute_dtype=dt, path="stream", reorder=False)
+    a.max_ADMM_iter = b.max_ADMM_iter = 3
+    xa = a.combined_loop(torch.from_numpy(y), print_info=False)
+    xb = b.combined_loop(torch.from_numpy(y), print_info=False)
+    assert rel(xa, xb) < (1e-12 if dt == torch.float64 else 1e-5)
+    a.close(); b.close()
