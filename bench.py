@@ -179,7 +179,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg3-leg", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -56,11 +56,10 @@ struct Engine : EngineBase {
     int* h_flag = nullptr;
     hipEvent_t ev_ring[LAG + 1] = {nullptr};
     int want_blocks = 2048;
-    struct TileMetaDev { int R = 0; int* tl_col = nullptr; float* tl_w = nullptr; int* halo = nullptr; int* h_rowptr = nullptr; int* h_col = nullptr; float* h_val = nullptr; };
+    struct TileMetaDev { int R = 0; int GW = 0; int* tl_col = nullptr; float* tl_w = nullptr; int* halo = nullptr; int* h_rowptr = nullptr; int* h_col = nullptr; float* h_val = nullptr; };
     TileMetaDev tmeta[3];         // W_u, W_d, W_d^T metadata for the tile size in use
     int cur_P = 0;                // partial rows written by the last row-kernel launch (k_rows or k_tile)
-    int use_tile = 0;             // experimental LDS-tiled spatial kernel on cluster-ordered graphs (MGADMM_TILE=1 enables):
-                                  // parity-tested, but slower than k_rows in round 1
+    int use_tile = 1;             // LDS-tiled spatial kernel on cluster-ordered graphs (reorder = 2); MGADMM_TILE=0 disables
     int64_t ws_bytes = 0;
     // LDS-resident fused path (float32, small graphs)
     struct LdsPlan {
@@ -128,17 +127,11 @@ struct Engine : EngineBase {
     bool make_tile_geom(const Geom& q, TileGeom& tg) const {
         if (!use_tile || g->reorder < 2 || g->mode != MGADMM_TEMPORAL_SPATIAL) return false;
         tg.T = T; tg.N = N; tg.B = q.B; tg.Bp = q.Bp; tg.VEC = q.VEC; tg.CH = q.CH;
-        // largest R <= 40 (multiple of 4) that still yields >= 512 workgroups, then the best-balanced R nearby
+        // tile size: 20 rows measured best on the 10k-node graph (12..24 are within 2 %); smaller tiles when
+        // the problem would otherwise not fill the machine (>= 512 workgroups wanted)
         const int rmax = 4 * TILE_MAXR;
-        int best = 0;
-        double best_score = -1;
-        for (int R = 8; R <= rmax; R += 4) {
-            const long blocks = (long)q.CH * ((N + R - 1) / R);
-            const long rounds = (blocks + 511) / 512;                  // 2 resident workgroups per CU
-            const double fill = (double)blocks / (double)(rounds * 512);
-            const double score = fill * (0.5 + 0.5 * R / rmax);      // prefer full machines and large tiles
-            if (score > best_score) { best_score = score; best = R; }
-        }
+        int best = 20;
+        while (best > 8 && (long)q.CH * ((N + best - 1) / best) < 512) best -= 4;
         if (const char* e = getenv("MGADMM_TILE_R")) { int rr = atoi(e); if (rr >= 4 && rr <= rmax && rr % 4 == 0) best = rr; }
         tg.R = best;
         tg.NTILE = (N + best - 1) / best;
@@ -151,9 +144,9 @@ struct Engine : EngineBase {
     }
 
     // host-side preprocessing of one CSR matrix for tile size R (see TileMeta in stream_kernels.h)
-    int tile_meta(int which, int R, TileMeta& out) {
+    int tile_meta(int which, int R, int TILE_GW, TileMeta& out) {
         TileMetaDev& d = tmeta[which];
-        if (d.R != R) {
+        if (d.R != R || d.GW != TILE_GW) {
             const HostCsr& src = which == 0 ? g->hWu : (which == 1 ? g->hWd : g->hWdT);
             HostCsr A;
             if (g->has_perm) mg_permute_csr(src, g->perm, g->iperm, A);
@@ -217,6 +210,7 @@ struct Engine : EngineBase {
             MG_HIP(hipMemcpy(d.h_col, hcol.data(), nh * sizeof(int), hipMemcpyHostToDevice));
             MG_HIP(hipMemcpy(d.h_val, hval.data(), nh * sizeof(float), hipMemcpyHostToDevice));
             d.R = R;
+            d.GW = TILE_GW;
         }
         out.tl_col = d.tl_col; out.tl_w = d.tl_w; out.halo = d.halo; out.h_rowptr = d.h_rowptr; out.h_col = d.h_col; out.h_val = d.h_val;
         return MGADMM_OK;
@@ -361,23 +355,46 @@ struct Engine : EngineBase {
     }
 
     // ---------------------------------------------------------------- launch helpers
+    template <class E, class = void>
+    struct is_elementwise : std::false_type {};
+    template <class E>
+    struct is_elementwise<E, std::void_t<decltype(E::ELEMENTWISE)>> : std::true_type {};
+
+    template <int VEC, class Epi, int TGW>
+    int launch_tile(const TileGeom& tg, const OpDesc& op, const TileMeta& tmv, const S* in, const Epi& epi, const int* live) {
+        auto fn = k_tile<S, VEC, Epi, TGW>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            MG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(fn, dim3(tg.grid), dim3(256), tg.lds_bytes, st, tg, op, tmv.tl_col, tmv.tl_w, tmv.halo, tmv.h_rowptr,
+                           tmv.h_col, tmv.h_val, in, epi, partials, live);
+        return MGADMM_OK;
+    }
+
     template <int VEC, int GW, class Epi>
     int rows_v(const Geom& q, const OpDesc& op, const S* in, const Epi& epi, const int* live, int tag, double bytes) {
         const bool timed = prof_open(tag, bytes);
         TileGeom tg;
         if (op.kind == OPK_SPATIAL && make_tile_geom(q, tg)) {
-            const int which = op.rowptr == g->Wu.rowptr ? 0 : (op.rowptr == g->Wd.rowptr ? 1 : 2);
-            TileMeta tmv;
-            MG_TRY(tile_meta(which, tg.R, tmv));
-            auto fn = k_tile<S, VEC, Epi>;
-            static bool attr_set = false;
-            if (!attr_set) {
-                MG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-                attr_set = true;
+            if constexpr (is_elementwise<Epi>::value) {
+                mg_set_error("rows: element-wise epilogue launched with a spatial operator");
+                return MGADMM_ERR_INVALID;
+            } else {
+                const int which = op.rowptr == g->Wu.rowptr ? 0 : (op.rowptr == g->Wd.rowptr ? 1 : 2);
+                // neighbour slots kept in VGPR lanes: 4 for W_u (k = 4), 6 for W_d, 8 for the ragged W_d^T rows
+                const DevCsr& dc = which == 0 ? g->Wu : (which == 1 ? g->Wd : g->WdT);
+                const int tgw = dc.max_row <= 4 ? 4 : (which == 2 || dc.max_row > 6 ? 8 : 6);
+                TileMeta tmv;
+                MG_TRY(tile_meta(which, tg.R, tgw, tmv));
+                switch (tgw) {
+                    case 4: MG_TRY((launch_tile<VEC, Epi, 4>(tg, op, tmv, in, epi, live))); break;
+                    case 6: MG_TRY((launch_tile<VEC, Epi, 6>(tg, op, tmv, in, epi, live))); break;
+                    default: MG_TRY((launch_tile<VEC, Epi, 8>(tg, op, tmv, in, epi, live))); break;
+                }
+                cur_P = tg.P;
             }
-            hipLaunchKernelGGL(fn, dim3(tg.grid), dim3(256), tg.lds_bytes, st, tg, op, tmv.tl_col, tmv.tl_w, tmv.halo, tmv.h_rowptr,
-                               tmv.h_col, tmv.h_val, in, epi, partials, live);
-            cur_P = tg.P;
         } else {
             hipLaunchKernelGGL((k_rows<S, VEC, Epi, GW>), dim3(q.grid), dim3(256), 0, st, q, op, op.rowptr, op.col, op.val,
                                op.band_w, in, epi, partials, live);

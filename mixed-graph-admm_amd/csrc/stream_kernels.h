@@ -264,17 +264,17 @@ struct TileGeom {
     int grid;     // 8 * TPX * CH workgroups
     int lds_bytes;
 };
-constexpr int TILE_MAXR = 10;   // rows per wave and time step (4 waves -> R <= 40)
-constexpr int TILE_GW = 6;      // neighbour slots per row held in VGPR lanes (TILE_MAXR*TILE_GW <= 64)
-constexpr int TILE_HMAX = 24;   // halo rows (out-of-tile neighbours) staged in LDS per tile and step
+constexpr int TILE_MAXR = 8;    // rows per wave and time step (4 waves -> R <= 32)
+constexpr int TILE_GW_MAX = 8;  // neighbour slots per row held in VGPR lanes: 4 (W_u), 6 (W_d) or 8 (W_d^T); MAXR*GW <= 64
+constexpr int TILE_HMAX = 16;   // halo rows (out-of-tile neighbours) staged in LDS per tile and step
 constexpr int TILE_HPW = TILE_HMAX / 4;   // halo rows loaded by one wave
 
 // Per-(matrix, R) metadata built on the host (Engine::tile_meta):
-//   tl_col/tl_w [N][TILE_GW] : the row's first TILE_GW "local" neighbours and weights.  Local index
+//   tl_col/tl_w [N][GW]      : the row's first GW "local" neighbours and weights.  Local index
 //                              0..R-1 = row of the own tile, R..R+H-1 = position in the tile's halo list;
 //                              unused slots point at the row itself with weight 0
 //   halo [NTILE][TILE_HMAX]  : global row indices of the tile's halo rows (-1 = unused)
-//   h_rowptr/h_col/h_val     : CSR of everything that did not fit (more than TILE_GW neighbours, more than
+//   h_rowptr/h_col/h_val     : CSR of everything that did not fit (more than GW neighbours, more than
 //                              TILE_HMAX halo rows): gathered from global memory, normally empty
 struct TileMeta {
     const int* tl_col;
@@ -285,7 +285,7 @@ struct TileMeta {
     const float* h_val;
 };
 
-template <typename S, int VEC, class Epi>
+template <typename S, int VEC, class Epi, int TILE_GW>
 __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* __restrict__ tl_col,
                                               const float* __restrict__ tl_w, const int* __restrict__ halo,
                                               const int* __restrict__ h_rowptr, const int* __restrict__ h_col,
@@ -337,34 +337,54 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
     const int shift = op.shift;
     const S* trow = tile + lane * VEC;
     S* hdst = tile + (size_t)g.R * W + lane * VEC;
+    auto step_t = [&](int sidx) { return shift > 0 ? g.T - 1 - sidx : sidx; };
+    // own rows of the first step; afterwards the own rows of step s+1 are requested while step s computes
+    Vec<S, VEC> own[TILE_MAXR];
+    {
+        const S* obase = in + (size_t)step_t(0) * g.N * g.Bp + col0;
+#pragma unroll
+        for (int j = 0; j < TILE_MAXR; ++j)
+            if (j < m) own[j] = ldv<S, VEC>(obase + (size_t)(n0 + wave + 4 * j) * g.Bp);
+    }
     for (int step = 0; step < g.T; ++step) {
-        const int t = shift > 0 ? g.T - 1 - step : step;
+        const int t = step_t(step);
         const int ts = t + shift;
         const bool tvalid = ts >= 0 && ts < g.T;
         S selfc = S(1);
         if (op.self_mode == SELF_LDR) selfc = (t >= 1) ? S(1) : S(0);
         else if (op.self_mode == SELF_LDRT) selfc = (t > 0 || op.q1) ? S(1) : S(0);
-        const S* obase = in + (size_t)t * g.N * g.Bp + col0;
         const S* gbase = in + (size_t)(tvalid ? ts : t) * g.N * g.Bp + col0;
-        // 1. own rows of this step and the halo rows of the gathered slice, all in flight together
-        Vec<S, VEC> own[TILE_MAXR];
-#pragma unroll
-        for (int j = 0; j < TILE_MAXR; ++j)
-            if (j < m) own[j] = ldv<S, VEC>(obase + (size_t)(n0 + wave + 4 * j) * g.Bp);
+        // 1. requests of this step, in the order they are needed: halo rows of the gathered slice, the
+        //    epilogue's operand rows, and the own rows of the NEXT step
+        Vec<S, VEC> hv[TILE_HPW];
         if (tvalid) {
-            Vec<S, VEC> hv[TILE_HPW];
 #pragma unroll
             for (int k = 0; k < TILE_HPW; ++k) {
                 const int hr = __builtin_amdgcn_readlane(hrow, k);
                 if (hr >= 0) hv[k] = ldv<S, VEC>(gbase + (size_t)hr * g.Bp);
             }
+        }
+        Vec<S, VEC> pre[TILE_MAXR];
+        if constexpr (Epi::HAS_PRE) {
+#pragma unroll
+            for (int j = 0; j < TILE_MAXR; ++j)
+                if (j < m) pre[j] = epi.pre(((size_t)t * g.N + n0 + wave + 4 * j) * g.Bp + col0);
+        }
+        Vec<S, VEC> ownn[TILE_MAXR];
+        {
+            const S* nbase = in + (size_t)step_t(min(step + 1, g.T - 1)) * g.N * g.Bp + col0;
+#pragma unroll
+            for (int j = 0; j < TILE_MAXR; ++j)
+                if (j < m) ownn[j] = ldv<S, VEC>(nbase + (size_t)(n0 + wave + 4 * j) * g.Bp);
+        }
+        if (tvalid) {
 #pragma unroll
             for (int k = 0; k < TILE_HPW; ++k) {
                 const int hr = __builtin_amdgcn_readlane(hrow, k);
                 if (hr >= 0) stv<S, VEC>(hdst + (size_t)(wave + 4 * k) * W, hv[k]);
             }
         }
-        if (shift == 0) {                               // Lu gathers from the slice it is loading
+        if (shift == 0) {                               // Lu gathers from the slice of this step
 #pragma unroll
             for (int j = 0; j < TILE_MAXR; ++j)
                 if (j < m) stv<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
@@ -405,7 +425,9 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
                 Vec<S, VEC> l;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) l.v[v] = selfc * own[j].v[v] - sum.v[v];
-                epi.row(t, ((size_t)t * g.N + i) * g.Bp + col0, own[j], l, acc);
+                const size_t off = ((size_t)t * g.N + i) * g.Bp + col0;
+                if constexpr (Epi::HAS_PRE) epi.row_pre(t, off, own[j], l, acc, pre[j]);
+                else epi.row(t, off, own[j], l, acc);
             }
         }
         __syncthreads();                                // every gather of this step is done
@@ -415,6 +437,8 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
             for (int j = 0; j < TILE_MAXR; ++j)
                 if (j < m) stv<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
         }
+#pragma unroll
+        for (int j = 0; j < TILE_MAXR; ++j) own[j] = ownn[j];
     }
 
     if (Epi::NRED > 0) {
@@ -443,6 +467,7 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
 template <typename S, int VEC>
 struct EpiStore {  // out = l
     static constexpr int NRED = 0;
+    static constexpr bool HAS_PRE = false;
     S* out;
     __device__ void begin(int) {}
     __device__ void row(int, size_t off, const Vec<S, VEC>&, const Vec<S, VEC>& l, S (*)[VEC]) { stv<S, VEC>(out + off, l); }
@@ -453,14 +478,26 @@ struct EpiStore {  // out = l
 template <typename S, int VEC>
 struct EpiLhs {
     static constexpr int NRED = 1;
+    static constexpr bool HAS_PRE = true;   // the row of p can be requested ahead of time (time-innermost sweep)
     const S* p;
     const S* mask;  // only for the stand-alone mgadmm_lhs entry point (LHS_x(x, mask))
     S* Ap;
     int hth, t_in;
     S c1, c2;
     __device__ void begin(int) {}
+    __device__ Vec<S, VEC> pre(size_t off) const {
+        if (p) return ldv<S, VEC>(p + off);
+        Vec<S, VEC> z;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) z.v[v] = S(0);
+        return z;
+    }
     __device__ void row(int t, size_t off, const Vec<S, VEC>& self, const Vec<S, VEC>& l, S (*acc)[VEC]) {
-        const Vec<S, VEC> pv = p ? ldv<S, VEC>(p + off) : self;
+        row_pre(t, off, self, l, acc, p ? ldv<S, VEC>(p + off) : self);
+    }
+    __device__ void row_pre(int t, size_t off, const Vec<S, VEC>& self, const Vec<S, VEC>& l, S (*acc)[VEC],
+                            const Vec<S, VEC>& pin) {
+        const Vec<S, VEC> pv = p ? pin : self;
         Vec<S, VEC> d;
         if (mask) d = ldv<S, VEC>(mask + off);
         else {
@@ -482,6 +519,7 @@ struct EpiLhs {
 template <typename S, int VEC>
 struct EpiCgInit {
     static constexpr int NRED = 1;
+    static constexpr bool HAS_PRE = false;
     const S* x0;    // nullptr: the gathered vector is x0 itself
     const S* rhs;
     const S* mask;  // nullptr: HtH = [t < t_in]
@@ -515,7 +553,9 @@ struct EpiCgInit {
 // x += alpha p ; r -= alpha Ap ; acc0 += r.r     (ADMM.py:352-355).  Gathered vector = p.
 template <typename S, int VEC>
 struct EpiCgUpdate {
+    static constexpr bool ELEMENTWISE = true;   // never launched with a spatial operator
     static constexpr int NRED = 1;
+    static constexpr bool HAS_PRE = false;
     const S* alpha;
     S *x, *r;
     const S* Ap;
@@ -541,7 +581,9 @@ struct EpiCgUpdate {
 // p = r + beta p     (ADMM.py:366).  Gathered vector = r.
 template <typename S, int VEC>
 struct EpiPUpdate {
+    static constexpr bool ELEMENTWISE = true;   // never launched with a spatial operator
     static constexpr int NRED = 0;
+    static constexpr bool HAS_PRE = false;
     const S* beta;
     S* p;
     S b[VEC];
@@ -560,7 +602,9 @@ struct EpiPUpdate {
 // out = a*in + b*w     (gamma + rho*phi ; gamma_u/2 + rho_u/2 x : ADMM.py:559, 579, 587)
 template <typename S, int VEC>
 struct EpiLin2 {
+    static constexpr bool ELEMENTWISE = true;   // never launched with a spatial operator
     static constexpr int NRED = 0;
+    static constexpr bool HAS_PRE = false;
     const S* w;
     S* out;
     S a, b;
@@ -578,6 +622,7 @@ struct EpiLin2 {
 template <typename S, int VEC>
 struct EpiRhsX {
     static constexpr int NRED = 0;
+    static constexpr bool HAS_PRE = false;
     const S *zu, *zd, *gu, *gd, *y;
     S* out;
     S rho_u, rho_d;
@@ -608,7 +653,9 @@ struct EpiRhsX {
 // acc: 0 ||x-x_old||^2, 1 ||x-zu||^2, 2 ||zu-zu_old||^2, 3 ||x-zd||^2, 4 ||zd-zd_old||^2, 5 ||Hx-y||^2
 template <typename S, int VEC>
 struct EpiDual {
+    static constexpr bool ELEMENTWISE = true;   // never launched with a spatial operator
     static constexpr int NRED = 6;
+    static constexpr bool HAS_PRE = false;
     const S *xold, *zu, *zuold, *zd, *zdold, *y, *mask;
     S *gu, *gd;
     S rho_u, rho_d;
@@ -667,6 +714,7 @@ __device__ __forceinline__ S soft_thr(S s, S thr) {
 template <typename S, int VEC>
 struct EpiPhi {
     static constexpr int NRED = 4;
+    static constexpr bool HAS_PRE = false;
     const S* phi_old;
     S* phi_new;
     S* gamma;
@@ -700,6 +748,7 @@ struct EpiPhi {
 template <typename S, int VEC>
 struct EpiPhiDirect {
     static constexpr int NRED = 0;
+    static constexpr bool HAS_PRE = false;
     const S* gamma;
     S* phi;
     S rho, thr;
@@ -717,6 +766,7 @@ struct EpiPhiDirect {
 template <typename S, int VEC>
 struct EpiDot {
     static constexpr int NRED = 1;
+    static constexpr bool HAS_PRE = false;
     __device__ void begin(int) {}
     __device__ void row(int, size_t, const Vec<S, VEC>& x, const Vec<S, VEC>& l, S (*acc)[VEC]) {
 #pragma unroll
