@@ -187,11 +187,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # one process per GPU; MGADMM_DIST_BACKEND=gloo (+ several ranks sharing a GPU) exists only to rehearse the
+    # multi-rank control flow on a one-GPU box
+    backend = os.environ.get("MGADMM_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    cdev = device if backend == "nccl" else torch.device("cpu")      # where collectives take their tensors
 
     n, B, cl, dl, info, desc = build_problem(args.workload)
     if args.batch:
@@ -212,8 +221,9 @@ def main():
         x = blk.combined_loop(y, print_info=False)
         gathered = None
         if world > 1:                       # the only exchange of the path: final gather of the x shards (RCCL/xGMI)
-            gathered = [torch.empty_like(x) for _ in range(world)] if rank == 0 else None
-            dist.gather(x, gathered, dst=0)
+            xs = x.to(cdev)
+            gathered = [torch.empty_like(xs) for _ in range(world)] if rank == 0 else None
+            dist.gather(xs, gathered, dst=0)
         pr = blk.prof_end() if prof else None
         return x, pr
 
@@ -224,7 +234,7 @@ def main():
     x, prof = run(args.steps, not args.no_prof)
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+    tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
