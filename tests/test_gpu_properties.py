@@ -1,0 +1,161 @@
+"""GPU parity at BASELINE.json's full sizes through size-independent properties (the oracle only finishes
+small cases in seconds): linearity, adjointness, symmetry, CG residuals, batch-permutation invariance,
+agreement between the independent execution paths (LDS-resident / streaming / LDS-tiled), repeatability.
+
+cfg2: PEMS04-shaped graph N=307, B=4096        cfg3: 10k-node kNN graph, B=512
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def _bench():
+    import bench
+    return bench
+
+
+def _solver(workload, **kw):
+    b = _bench()
+    n, B, cl, dl, info, _ = b.build_problem(workload)
+    import mgadmm
+    blk = mgadmm.ADMM_algorithm({"n_nodes": n}, info, use_kNN=True, k=4, u_sigma=50, d_sigma=50, tables=(cl, dl),
+                                record_cg_coeffs=False, **kw)
+    return blk, n, B
+
+
+def rel(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.fixture(scope="module")
+def cfg3():
+    blk, n, B = _solver("cfg3", bug_compat=False)
+    yield blk, n, B
+    blk.close()
+
+
+def test_cfg3_operators_are_linear_and_adjoint(cfg3):
+    blk, n, B = cfg3
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(B, 24, n, 1, device="cuda", generator=g)
+    y = torch.randn(B, 24, n, 1, device="cuda", generator=g)
+    for nm in ("Lu", "Ldr", "Ldr_T", "cLdr"):
+        op = getattr(blk, "apply_op_" + nm)
+        lin = op(2.0 * x - 0.5 * y)
+        assert rel(lin, 2.0 * op(x) - 0.5 * op(y)) < 2e-6, nm
+    # exact transpose with the quirk off: <Ldr x, y> = <x, Ldr^T y>, per sample
+    a = (blk.apply_op_Ldr(x) * y).sum((1, 2, 3)).double()
+    b = (x * blk.apply_op_Ldr_T(y)).sum((1, 2, 3)).double()
+    assert float(((a - b).abs() / (a.abs() + 1e3)).max()) < 1e-4
+    # cLdr = Ldr^T Ldr is symmetric positive semi-definite
+    c1 = (blk.apply_op_cLdr(x) * y).sum().item()
+    c2 = (x * blk.apply_op_cLdr(y)).sum().item()
+    assert abs(c1 - c2) < 1e-4 * (abs(c1) + 1e3)
+    assert float((x * blk.apply_op_cLdr(x)).sum((1, 2, 3)).min()) >= 0.0
+    # Ldr annihilates t = 0 and is the identity minus a row-stochastic average: constants map to 0 for t >= 1
+    one = torch.ones(2, 24, n, 1, device="cuda")
+    assert float(blk.apply_op_Ldr(one).abs().max()) < 1e-5
+
+
+def test_cfg3_tiled_and_plain_kernels_agree(cfg3, monkeypatch):
+    blk, n, B = cfg3
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(B, 24, n, 1, device="cuda", generator=g)
+    monkeypatch.setenv("MGADMM_TILE", "0")
+    plain, _, _ = _solver("cfg3", bug_compat=False)
+    for nm in ("apply_op_Lu", "apply_op_Ldr", "apply_op_Ldr_T", "apply_op_cLdr", "LHS_x", "LHS_zu", "LHS_zd"):
+        assert rel(getattr(blk, nm)(x), getattr(plain, nm)(x)) < 1e-6, nm
+    plain.close()
+
+
+def test_cfg3_cg_solves_the_system_per_sample(cfg3):
+    """After CG_solver, A x = b holds to the recursive-residual tolerance and every sample reports its own count."""
+    blk, n, B = cfg3
+    g = torch.Generator(device="cuda").manual_seed(2)
+    scale = torch.logspace(-2, 2, 64, device="cuda").reshape(64, 1, 1, 1)
+    rhs = torch.randn(64, 24, n, 1, device="cuda", generator=g) * scale
+    for fn in (blk.LHS_x, blk.LHS_zu, blk.LHS_zd):
+        x, iters, al, be = blk.CG_solver(fn, rhs)
+        assert int(iters.min()) > 0 and int(iters.max()) < 100
+        res = (fn(x) - rhs).flatten(1).norm(dim=1) / rhs.flatten(1).norm(dim=1)
+        assert float(res.max()) < 1e-5
+        assert len(set(iters.tolist())) > 1            # per-sample convergence: different scales stop at different iterations
+
+
+def test_cfg3_solve_repeatable_and_batch_permutation_invariant(cfg3):
+    blk, n, B = cfg3
+    b = _bench()
+    y = b.synth_y(n, 128, 12, seed=3, offset=0, device=torch.device("cuda"))
+    blk.max_ADMM_iter = 3
+    blk.check_stop = False
+    x1 = blk.combined_loop(y, print_info=False)
+    h1 = np.array(blk.p_res_list)
+    blk._reset_history()
+    x2 = blk.combined_loop(y, print_info=False)
+    assert torch.equal(x1, x2) and np.array_equal(h1, np.array(blk.p_res_list))      # bitwise repeatable
+    perm = torch.randperm(128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    blk._reset_history()
+    xp = blk.combined_loop(y[perm].contiguous(), print_info=False)
+    assert torch.equal(xp, x1[perm])                     # samples are independent optimisations
+    np.testing.assert_allclose(np.array(blk.p_res_list), h1, rtol=1e-6)
+    assert torch.isfinite(x1).all()
+
+
+def test_cfg2_full_batch_lds_vs_stream_and_permutation():
+    """Config 2 at full size (B = 4096): the two independent execution paths agree sample by sample."""
+    b = _bench()
+    lds, n, B = _solver("cfg2", path="lds")
+    stream, _, _ = _solver("cfg2", path="stream")
+    y = b.synth_y(n, B, 12, seed=1, offset=0, device=torch.device("cuda"))
+    for blk in (lds, stream):
+        blk.max_ADMM_iter = 3
+        blk.check_stop = False
+    xl = lds.combined_loop(y, print_info=False)
+    xs = stream.combined_loop(y, print_info=False)
+    err = (xl - xs).flatten(1).norm(dim=1) / xs.flatten(1).norm(dim=1)
+    assert float(err.max()) < 2e-6
+    np.testing.assert_allclose(np.array(lds.p_res_list), np.array(stream.p_res_list), rtol=1e-4)
+    np.testing.assert_allclose(np.array(lds.d_res_list), np.array(stream.d_res_list), rtol=1e-4)
+    assert (torch.stack(lds.CG_iter_x) - torch.stack(stream.CG_iter_x)).abs().max() <= 1
+    # every window is its own problem: solving a sub-batch gives the same windows
+    sub = lds.combined_loop(y[1000:1064].contiguous(), print_info=False)
+    assert torch.equal(sub, xl[1000:1064])
+    lds.close(); stream.close()
+
+
+def test_cfg5_fp32_vs_fp64_tolerance_sweep():
+    """BASELINE config 5: PEMS04 graph, 'None' ablation (asymmetric L_d), float32 HIP (both paths) against the
+    float64 HIP kernels (themselves pinned to the reference at 1e-10) on 64 windows, per-iteration tolerances
+    of SURVEY 8c: rel. x error <= 1e-5, residual history <= 1e-3, CG counts within +-1."""
+    b = _bench()
+    n, B, cl, dl, info, _ = b.build_problem("cfg2")
+    import mgadmm
+    y = b.synth_y(n, 64, 12, seed=1, offset=0, device=torch.device("cuda")).double()
+    runs = {}
+    for name, kw in (("f64", dict(compute_dtype=torch.float64)), ("lds", dict(path="lds")), ("stream", dict(path="stream"))):
+        blk = mgadmm.ADMM_algorithm({"n_nodes": n}, info, use_kNN=True, k=4, u_sigma=50, d_sigma=50, tables=(cl, dl),
+                                    record_cg_coeffs=False, **kw)
+        blk.max_ADMM_iter = 50
+        blk.check_stop = False
+        x = blk.combined_loop(y, print_info=False)
+        runs[name] = (x, np.array(blk.p_res_list), np.array(blk.d_res_list), torch.stack(blk.CG_iter_x),
+                      torch.stack(blk.CG_iter_zu), torch.stack(blk.CG_iter_zd))
+        blk.close()
+    ref = runs["f64"]
+    for name in ("lds", "stream"):
+        x, p, d, ix, izu, izd = runs[name]
+        err = (x - ref[0]).flatten(1).norm(dim=1) / ref[0].flatten(1).norm(dim=1)
+        assert float(err.max()) < 1e-5, name
+        np.testing.assert_allclose(p, ref[1], rtol=1e-3)
+        np.testing.assert_allclose(d, ref[2], rtol=1e-3)
+        for a, r in ((ix, ref[3]), (izu, ref[4]), (izd, ref[5])):
+            assert int((a - r).abs().max()) <= 1, name
