@@ -5,7 +5,8 @@
 // every residual / regulariser of the history.  Inside a CG solve nothing touches HBM:
 //   * thread (g, i) owns node i at TPG consecutive time steps t0 = g*TPG ...; x, r, p, Ap of those
 //     elements live in registers for the whole solve;
-//   * the CG direction p (and q = Ldr p) live in LDS so that neighbours can be gathered;
+//   * a copy of the CG direction p (and of q = Ldr p) lives in LDS so that neighbours can be gathered --
+//     the only LDS traffic of an iteration is those gathers (aligned ds_read_b128) and one store of p and q;
 //   * the three CSR matrices (W_u, W_d, W_d^T as packed {col, weight} pairs) live in LDS too; a thread
 //     reads each entry of ITS node's row once per operator application and applies it to its TPG time steps;
 //   * p.Ap and r.r are reduced with wave shuffles + a 16-entry LDS exchange in fixed order (repeatable);
@@ -86,12 +87,15 @@ struct BlockRed {
 
 // vector access to TPG consecutive floats in LDS (alignment: TPG*4 B when TPG is a multiple of 4, 8 B when
 // even -- guaranteed by the node-major [N][T] LDS layout with TPG | T)
+typedef float lds_f4 __attribute__((ext_vector_type(4)));
 template <int TPG>
 __device__ __forceinline__ void lds_load(const float* p, float (&v)[TPG]) {
     if constexpr (TPG % 4 == 0) {
 #pragma unroll
         for (int j = 0; j < TPG / 4; ++j) {
-            const float4 q = reinterpret_cast<const float4*>(p)[j];
+            // native vector type + assume_aligned: a struct float4 load gets split into align-4 scalars and
+            // re-fused as ds_read_b96/read2_b32 (32-bank forms); this stays one ds_read_b128
+            const lds_f4 q = static_cast<const lds_f4*>(__builtin_assume_aligned(p, 16))[j];
             v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
         }
     } else if constexpr (TPG % 2 == 0) {
@@ -130,7 +134,6 @@ struct LdsCtx {
     bool active;
     float* P;
     float* Q;
-    float* AP;
     const int2* en_u; const int2* en_d; const int2* en_t;
     int u0, u1, d0, d1, t0e, t1e;   // this node's CSR row bounds
     int skip, q1;
@@ -139,31 +142,53 @@ struct LdsCtx {
     __device__ __forceinline__ int gl(int k) const { return (t0 + k) * N + i; }   // HBM index
     __device__ __forceinline__ int own() const { return i * TS + t0; }            // LDS index of element k = 0
 
-    // acc[k] = sum_e w_e * SRC[col_e][t0+k+shift]     (0 outside [0,T))
+    // acc[k] = sum_e w_e * SRC[col_e][t0+k+shift]     (0 outside [0,T)).  Entries carry the LDS float offset of
+    // the neighbour's row (col*TS, precomputed on the host), so a row address is one add.
     __device__ __forceinline__ void gather(const float* SRC, const int2* EN, int e0, int e1, int shift, float (&acc)[TPG]) const {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
+        const float* base = SRC + t0;
+        // A shifted window [t0-1, t0+TPG-2] or [t0+1, t0+TPG] is read as the ALIGNED run [t0, t0+TPG-1] plus one
+        // more aligned 16-byte group that holds the edge element: all reads stay conflict-free ds_read_b128
+        // (unaligned b96 / read2_b32 forms use 32 banks and collide 4-way at this row stride).  `keep` stops
+        // the compiler from narrowing the vector loads to the components that are used.
+        const bool lo_ok = t0 > 0, hi_ok = t0 + TPG < T;
+        const int goff = (TPG % 4 == 0) ? (shift < 0 ? (lo_ok ? -4 : 0) : TPG) : 0;   // edge group, TS >= T + 4 pads the tail
+        const float emask = shift < 0 ? (lo_ok ? 1.f : 0.f) : (hi_ok ? 1.f : 0.f);
+        const int eoff = shift < 0 ? (lo_ok ? -1 : 0) : (hi_ok ? TPG : TPG - 1);      // scalar fallback (TPG % 4 != 0)
         int2 nx = EN[e0];                   // one entry ahead (arrays are padded: reading EN[e1] is safe)
         for (int e = e0; e < e1; ++e) {
             const int2 en = nx;
             nx = EN[e + 1];
             const float w = __int_as_float(en.y);
-            const float* row = SRC + en.x * TS + t0;
+            const float* row = base + en.x;
             float v[TPG];
             lds_load<TPG>(row, v);
             if (shift == 0) {
 #pragma unroll
                 for (int k = 0; k < TPG; ++k) acc[k] += w * v[k];
-            } else if (shift < 0) {
-                const float edge = (t0 > 0) ? row[-1] : 0.f;
-                acc[0] += w * edge;
-#pragma unroll
-                for (int k = 1; k < TPG; ++k) acc[k] += w * v[k - 1];
             } else {
-                const float edge = (t0 + TPG < T) ? row[TPG] : 0.f;
+                float edge;
+                if constexpr (TPG % 4 == 0) {
+                    float eg[4];
+                    lds_load<4>(row + goff, eg);
 #pragma unroll
-                for (int k = 0; k < TPG - 1; ++k) acc[k] += w * v[k + 1];
-                acc[TPG - 1] += w * edge;
+                    for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(eg[k]));
+#pragma unroll
+                    for (int k = 0; k < TPG; ++k) asm volatile("" ::"v"(v[k]));
+                    edge = shift < 0 ? (lo_ok ? eg[3] : 0.f) : (hi_ok ? eg[0] : 0.f);   // select: the pad words are not initialised
+                } else {
+                    edge = row[eoff] * emask;
+                }
+                if (shift < 0) {
+                    acc[0] += w * edge;
+#pragma unroll
+                    for (int k = 1; k < TPG; ++k) acc[k] += w * v[k - 1];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < TPG - 1; ++k) acc[k] += w * v[k + 1];
+                    acc[TPG - 1] += w * edge;
+                }
             }
         }
     }
@@ -194,29 +219,26 @@ struct LdsCtx {
             }
         }
     }
-    // l = Lu(src): own elements and neighbours both from SRC (LDS)     ADMM.py:138-148
-    __device__ __forceinline__ void op_lu(const float* SRC, float (&l)[TPG]) const {
-        float acc[TPG], self[TPG];
+    // l = Lu(src): neighbours from SRC (LDS), the thread's own elements of src from registers (self)     ADMM.py:138-148
+    __device__ __forceinline__ void op_lu(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
+        float acc[TPG];
         gather(SRC, en_u, u0, u1, 0, acc);
-        lds_load<TPG>(SRC + own(), self);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = self[k] - acc[k];
     }
     // l = Ldr(src)      ADMM.py:150-177
-    __device__ __forceinline__ void op_ldr(const float* SRC, float (&l)[TPG]) const {
-        float acc[TPG], self[TPG];
+    __device__ __forceinline__ void op_ldr(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
+        float acc[TPG];
         if constexpr (!BAND) gather(SRC, en_d, d0, d1, -1, acc);
         else band_back(SRC, acc);
-        lds_load<TPG>(SRC + own(), self);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((t0 + k >= 1) ? self[k] : 0.f) - acc[k];
     }
     // l = Ldr_T(src)    ADMM.py:179-223 (q1: identity kept on the t=0 block)
-    __device__ __forceinline__ void op_ldrt(const float* SRC, float (&l)[TPG]) const {
-        float acc[TPG], self[TPG];
+    __device__ __forceinline__ void op_ldrt(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
+        float acc[TPG];
         if constexpr (!BAND) gather(SRC, en_t, t0e, t1e, +1, acc);
         else band_fwd(SRC, acc);
-        lds_load<TPG>(SRC + own(), self);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((t0 + k > 0 || q1) ? self[k] : 0.f) - acc[k];
     }
@@ -233,86 +255,74 @@ struct LdsCtx {
     }
 };
 
-// AP = A v for the vector v held in ctx.P (LDS):
+// av = (A v) on the thread's own elements, for the vector v held in ctx.P (LDS; own elements also in v):
 //   KIND 1: d*v + c1*v + c2*Ldr_T(Ldr v) ; KIND 2: c1*v + c2*Lu v ; KIND 0: d*v + c1*v
 // d = dg[el] when dg != nullptr (mask values, global memory), else [hth && t < t_in].
-// Own elements of the result go to ctx.AP (LDS); returns sum_k v_k * (A v)_k of the own elements.
-// Uses ctx.Q as scratch; contains a barrier for KIND 1.  Callers separate successive calls by barriers.
+// Returns sum_k v_k * (A v)_k of the own elements.  Uses ctx.Q as scratch; contains a barrier for KIND 1.
+// Callers separate successive calls by barriers.
 template <int TPG, bool BAND, int KIND>
-__device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND>& c, const float* dg, int hth, int t_in, float c1, float c2) {
+__device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND>& c, const float (&v)[TPG], float (&av)[TPG], const float* dg, int hth,
+                                           int t_in, float c1, float c2) {
     float l[TPG];
 #pragma unroll
     for (int k = 0; k < TPG; ++k) l[k] = 0.f;
     if (KIND == 1) {
+        float q[TPG];
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) q[k] = 0.f;
         if (c.active) {
-            float q[TPG];
-            c.op_ldr(c.P, q);
+            c.op_ldr(c.P, v, q);
             c.put(c.Q, q);
         }
         __syncthreads();
-        if (c.active) c.op_ldrt(c.Q, l);
+        if (c.active) c.op_ldrt(c.Q, q, l);
     } else if (KIND == 2) {
-        if (c.active) c.op_lu(c.P, l);
+        if (c.active) c.op_lu(c.P, v, l);
     }
     float part = 0.f;
-    if (c.active) {
-        float v[TPG], av[TPG];
-        lds_load<TPG>(c.P + c.own(), v);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) {
-            float d = 0.f;
-            if (KIND != 2) d = dg ? dg[c.gl(k)] : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
-            av[k] = d * v[k] + c1 * v[k] + c2 * l[k];
-            part += v[k] * av[k];
-        }
-        lds_store<TPG>(c.AP + c.own(), av);
+    for (int k = 0; k < TPG; ++k) {
+        float d = 0.f;
+        if (KIND != 2) d = dg ? (c.active ? dg[c.gl(k)] : 0.f) : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
+        av[k] = d * v[k] + c1 * v[k] + c2 * l[k];
+        part += v[k] * av[k];
     }
     return part;
 }
 
 // CG_solver (ADMM.py:329-368) for one sample.  x, r of the own elements live in registers, the direction
-// p in LDS (ctx.P), A p in LDS (ctx.AP).  x holds x0 on entry and the solution on exit.  dmask: diagonal
+// p in registers with a copy in LDS (ctx.P) for the neighbours' gathers, A p in registers.  x holds x0 on entry and the solution on exit.  dmask: diagonal
 // of the initial residual when a mask is given (global memory); the iterations always use [t<t_in]
 // (quirk Q2).  Returns the iteration count (k+1) or -1.  Entry requirement: no thread still reads P/Q.
 template <int TPG, bool BAND, int KIND>
 __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
                       int hth, int t_in, float c1, float c2, int max_cg, double tol, float* ah, float* bh, int Bp,
                       int* nonfinite) {
-    float r[TPG];
-#pragma unroll
-    for (int k = 0; k < TPG; ++k) r[k] = 0.f;
+    float r[TPG], pv[TPG], av[TPG];
     c.put(c.P, x);
     __syncthreads();
-    (void)lds_apply<TPG, BAND, KIND>(c, dmask, hth, t_in, c1, c2);
+    (void)lds_apply<TPG, BAND, KIND>(c, x, av, dmask, hth, t_in, c1, c2);
     float part = 0.f;
-    if (c.active) {
-        float av[TPG];
-        lds_load<TPG>(c.AP + c.own(), av);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) {
-            r[k] = rhs[k] - av[k];
-            part += r[k] * r[k];
-        }
+    for (int k = 0; k < TPG; ++k) {
+        r[k] = c.active ? rhs[k] - av[k] : 0.f;
+        pv[k] = r[k];                    // p = r
+        part += r[k] * r[k];
     }
     float rr = (float)br.sum(part);      // barrier: every read of P (= x0) is done
-    c.put(c.P, r);                       // p = r
+    c.put(c.P, pv);
     int iters = -1;
     for (int it = 0; it < max_cg; ++it) {
         __syncthreads();                 // p complete in LDS
-        part = lds_apply<TPG, BAND, KIND>(c, nullptr, hth, t_in, c1, c2);
+        part = lds_apply<TPG, BAND, KIND>(c, pv, av, nullptr, hth, t_in, c1, c2);
         const float pAp = (float)br.sum(part);   // barrier: every gather from P/Q of this iteration is done
         const float alpha = rr / pAp;
         part = 0.f;
-        if (c.active) {
-            float pv[TPG], av[TPG];
-            lds_load<TPG>(c.P + c.own(), pv);
-            lds_load<TPG>(c.AP + c.own(), av);
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) {
-                x[k] = x[k] + alpha * pv[k];
-                r[k] = r[k] - alpha * av[k];
-                part += r[k] * r[k];
-            }
+        for (int k = 0; k < TPG; ++k) {
+            x[k] = x[k] + alpha * pv[k];
+            r[k] = r[k] - alpha * av[k];
+            part += r[k] * r[k];
         }
         const float rrn = (float)br.sum(part);
         const float beta = rrn / rr;
@@ -329,13 +339,9 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, 
             iters = it + 1;
             break;
         }
-        if (c.active) {
-            float pv[TPG];
-            lds_load<TPG>(c.P + c.own(), pv);
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) pv[k] = r[k] + beta * pv[k];
-            lds_store<TPG>(c.P + c.own(), pv);
-        }
+        for (int k = 0; k < TPG; ++k) pv[k] = r[k] + beta * pv[k];
+        c.put(c.P, pv);
     }
     return iters;
 }
@@ -346,8 +352,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
     float* P = reinterpret_cast<float*>(lds_raw);
     const int LN = a.N * a.TS;                                         // floats per LDS vector (TS % 4 == 0 or TS == T)
     float* Q = P + LN;
-    float* AP = Q + LN;
-    float* red = AP + LN + ((4 - (LN & 3)) & 3);                       // 16-byte aligned, 2 x 16 floats
+    float* red = Q + LN + ((4 - (LN & 3)) & 3);                       // 16-byte aligned, 2 x 16 floats
     int* csr = reinterpret_cast<int*>(red + 32);
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
     const int g = c.active ? tid / a.N : 0;
     c.i = c.active ? tid - g * a.N : 0;
     c.t0 = g * TPG;
-    c.P = P; c.Q = Q; c.AP = AP;
+    c.P = P; c.Q = Q;
     c.skip = a.skip; c.q1 = a.q1; c.band_w = a.band_w;
     c.en_u = reinterpret_cast<const int2*>(csr + a.off_en_u);
     c.en_d = reinterpret_cast<const int2*>(csr + a.off_en_d);
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
         for (int k = 0; k < TPG; ++k) ph[k] = 0.f;
         c.put(P, x);
         __syncthreads();
-        if (c.active) c.op_ldr(P, ph);
+        if (c.active) c.op_ldr(P, x, ph);
         c.putg(phi, ph);
         __syncthreads();
     }
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
             for (int k = 0; k < TPG; ++k) v[k] = c.active ? gam[c.gl(k)] + a.rho * phi[c.gl(k)] : 0.f;
             c.put(P, v);
             __syncthreads();
-            if (c.active) c.op_ldrt(P, l);
+            if (c.active) c.op_ldrt(P, v, l);
             __syncthreads();
         }
 #pragma unroll
@@ -530,16 +535,14 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
     // ---- phi prox, gamma update, Ldr/Lu based diagnostics (ADMM.py:600-606, 619, 627-637)
     double m_priphi = 0, m_dualphi = 0, m_dgtv = 0, m_dglr = 0, m_glr = 0;
     __syncthreads();          // every LDS read of the last CG is done
-    if (c.active) {
-        float xv[TPG];
+    float xv[TPG];
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) xv[k] = xn[c.gl(k)];
-        c.put(P, xv);
-    }
+    for (int k = 0; k < TPG; ++k) xv[k] = c.active ? xn[c.gl(k)] : 0.f;
+    c.put(P, xv);
     __syncthreads();
     if (c.active) {
         float l[TPG];
-        c.op_ldr(P, l);
+        c.op_ldr(P, xv, l);
         const float thr = a.mu_d1 / a.rho;
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
@@ -558,9 +561,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
                 gam[e] = gv + a.rho * dd;
             }
         }
-        c.op_lu(P, l);
-        float xv[TPG];
-        lds_load<TPG>(P + c.own(), xv);
+        c.op_lu(P, xv, l);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) m_glr += (double)xv[k] * (double)l[k];
     }

@@ -860,7 +860,7 @@ struct Engine : EngineBase {
         // fall back to the unpadded stride when the padded vectors do not fit
         int ts = (T + 3) / 4 * 4;
         if (((ts / 4) & 1) == 0) ts += 4;
-        auto bytes_for = [&](int stride) { return (size_t)12 * N * stride + 16 + 32 * sizeof(float) + (size_t)4 * off; };
+        auto bytes_for = [&](int stride) { return (size_t)8 * N * stride + 16 + 32 * sizeof(float) +  (size_t)4 * off; };   // P, Q + reduction slots + CSR image
         if (bytes_for(ts) > 160 * 1024) ts = T;
         lds.TS = ts;
         lds.lds_bytes = bytes_for(ts);
@@ -873,7 +873,7 @@ struct Engine : EngineBase {
         auto put_csr = [&](const HostCsr& h, int off_rp, int off_en) {
             for (int i = 0; i <= N; ++i) img[off_rp + i] = h.rowptr[i];
             for (int e = 0; e < h.nnz(); ++e) {
-                img[off_en + 2 * e] = h.col[e];
+                img[off_en + 2 * e] = h.col[e] * lds.TS;       // LDS float offset of the neighbour's time row
                 memcpy(&img[off_en + 2 * e + 1], &h.val[e], 4);
             }
         };
