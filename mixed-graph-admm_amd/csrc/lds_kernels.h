@@ -142,54 +142,75 @@ struct LdsCtx {
     __device__ __forceinline__ int gl(int k) const { return (t0 + k) * N + i; }   // HBM index
     __device__ __forceinline__ int own() const { return i * TS + t0; }            // LDS index of element k = 0
 
+    // One CSR entry's window of the neighbour row: v[k] = SRC[col][t0+k] with, for a shifted gather, the edge
+    // element (t0-1 resp. t0+TPG, 0 outside [0,T)) in the slot of the window element the shift does not use
+    // (v[TPG-1] resp. v[0]) -- i.e. the window ROTATED by one, so that acc[k] += w*v[k] needs no register
+    // shuffles for the packed FMAs; gather() undoes the rotation once after its loop.
+    //   A shifted window [t0-1, t0+TPG-2] or [t0+1, t0+TPG] is read as the ALIGNED run [t0, t0+TPG-1] plus one
+    //   more aligned 16-byte group holding the edge element: every read is a conflict-free ds_read_b128
+    //   (unaligned b96 / read2_b32 forms use 32 banks and collide 4-way at this row stride).  The empty asm
+    //   statements stop the compiler from narrowing the vector loads to the components that are used.
+    __device__ __forceinline__ void fetch(const float* base, int coloff, int shift, float (&v)[TPG]) const {
+        const float* row = base + coloff;
+        lds_load<TPG>(row, v);
+        if (shift == 0) return;
+        const bool lo_ok = t0 > 0, hi_ok = t0 + TPG < T;
+        float edge;
+        if constexpr (TPG % 4 == 0) {
+            const int goff = shift < 0 ? (lo_ok ? -4 : 0) : TPG;      // TS >= T + 4 pads the tail (or the next row follows)
+            float eg[4];
+            lds_load<4>(row + goff, eg);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(eg[k]));
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) asm volatile("" ::"v"(v[k]));
+            edge = shift < 0 ? (lo_ok ? eg[3] : 0.f) : (hi_ok ? eg[0] : 0.f);   // select: the pad words are not initialised
+        } else {
+            const int eoff = shift < 0 ? (lo_ok ? -1 : 0) : (hi_ok ? TPG : TPG - 1);
+            const float emask = shift < 0 ? (lo_ok ? 1.f : 0.f) : (hi_ok ? 1.f : 0.f);
+            edge = row[eoff] * emask;
+        }
+        v[shift < 0 ? TPG - 1 : 0] = edge;
+    }
     // acc[k] = sum_e w_e * SRC[col_e][t0+k+shift]     (0 outside [0,T)).  Entries carry the LDS float offset of
-    // the neighbour's row (col*TS, precomputed on the host), so a row address is one add.
+    // the neighbour's row (col*TS, precomputed on the host).  Two entries are in flight per trip (their LDS
+    // reads are issued together, the next pair of entries is fetched meanwhile); the sum runs in entry order.
     __device__ __forceinline__ void gather(const float* SRC, const int2* EN, int e0, int e1, int shift, float (&acc)[TPG]) const {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
         const float* base = SRC + t0;
-        // A shifted window [t0-1, t0+TPG-2] or [t0+1, t0+TPG] is read as the ALIGNED run [t0, t0+TPG-1] plus one
-        // more aligned 16-byte group that holds the edge element: all reads stay conflict-free ds_read_b128
-        // (unaligned b96 / read2_b32 forms use 32 banks and collide 4-way at this row stride).  `keep` stops
-        // the compiler from narrowing the vector loads to the components that are used.
-        const bool lo_ok = t0 > 0, hi_ok = t0 + TPG < T;
-        const int goff = (TPG % 4 == 0) ? (shift < 0 ? (lo_ok ? -4 : 0) : TPG) : 0;   // edge group, TS >= T + 4 pads the tail
-        const float emask = shift < 0 ? (lo_ok ? 1.f : 0.f) : (hi_ok ? 1.f : 0.f);
-        const int eoff = shift < 0 ? (lo_ok ? -1 : 0) : (hi_ok ? TPG : TPG - 1);      // scalar fallback (TPG % 4 != 0)
-        int2 nx = EN[e0];                   // one entry ahead (arrays are padded: reading EN[e1] is safe)
-        for (int e = e0; e < e1; ++e) {
-            const int2 en = nx;
-            nx = EN[e + 1];
-            const float w = __int_as_float(en.y);
-            const float* row = base + en.x;
-            float v[TPG];
-            lds_load<TPG>(row, v);
-            if (shift == 0) {
+        int2 na = EN[e0], nb = EN[e0 + 1];          // the arrays are padded by 3 entries: reads past e1 are safe
+        int e = e0;
+        for (; e + 1 < e1; e += 2) {
+            const int2 ea = na, eb = nb;
+            float va[TPG], vb[TPG];
+            fetch(base, ea.x, shift, va);
+            fetch(base, eb.x, shift, vb);
+            na = EN[e + 2];
+            nb = EN[e + 3];
+            const float wa = __int_as_float(ea.y), wb = __int_as_float(eb.y);
 #pragma unroll
-                for (int k = 0; k < TPG; ++k) acc[k] += w * v[k];
-            } else {
-                float edge;
-                if constexpr (TPG % 4 == 0) {
-                    float eg[4];
-                    lds_load<4>(row + goff, eg);
+            for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(eg[k]));
+            for (int k = 0; k < TPG; ++k) acc[k] += wb * vb[k];
+        }
+        if (e < e1) {
+            float va[TPG];
+            fetch(base, na.x, shift, va);
+            const float wa = __int_as_float(na.y);
 #pragma unroll
-                    for (int k = 0; k < TPG; ++k) asm volatile("" ::"v"(v[k]));
-                    edge = shift < 0 ? (lo_ok ? eg[3] : 0.f) : (hi_ok ? eg[0] : 0.f);   // select: the pad words are not initialised
-                } else {
-                    edge = row[eoff] * emask;
-                }
-                if (shift < 0) {
-                    acc[0] += w * edge;
+            for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
+        }
+        if (shift < 0) {
+            const float last = acc[TPG - 1];
 #pragma unroll
-                    for (int k = 1; k < TPG; ++k) acc[k] += w * v[k - 1];
-                } else {
+            for (int k = TPG - 1; k >= 1; --k) acc[k] = acc[k - 1];
+            acc[0] = last;
+        } else if (shift > 0) {
+            const float first = acc[0];
 #pragma unroll
-                    for (int k = 0; k < TPG - 1; ++k) acc[k] += w * v[k + 1];
-                    acc[TPG - 1] += w * edge;
-                }
-            }
+            for (int k = 0; k < TPG - 1; ++k) acc[k] = acc[k + 1];
+            acc[TPG - 1] = first;
         }
     }
     // band (line-graph) stencils on the node's own time row
@@ -232,7 +253,7 @@ struct LdsCtx {
         if constexpr (!BAND) gather(SRC, en_d, d0, d1, -1, acc);
         else band_back(SRC, acc);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) l[k] = ((t0 + k >= 1) ? self[k] : 0.f) - acc[k];
+        for (int k = 0; k < TPG; ++k) l[k] = ((k >= 1 || t0 >= 1) ? self[k] : 0.f) - acc[k];
     }
     // l = Ldr_T(src)    ADMM.py:179-223 (q1: identity kept on the t=0 block)
     __device__ __forceinline__ void op_ldrt(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
@@ -240,7 +261,7 @@ struct LdsCtx {
         if constexpr (!BAND) gather(SRC, en_t, t0e, t1e, +1, acc);
         else band_fwd(SRC, acc);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) l[k] = ((t0 + k > 0 || q1) ? self[k] : 0.f) - acc[k];
+        for (int k = 0; k < TPG; ++k) l[k] = ((k > 0 || t0 > 0 || q1) ? self[k] : 0.f) - acc[k];
     }
     // own elements -> LDS vector
     __device__ __forceinline__ void put(float* DST, const float (&v)[TPG]) const {
@@ -256,13 +277,13 @@ struct LdsCtx {
 };
 
 // av = (A v) on the thread's own elements, for the vector v held in ctx.P (LDS; own elements also in v):
-//   KIND 1: d*v + c1*v + c2*Ldr_T(Ldr v) ; KIND 2: c1*v + c2*Lu v ; KIND 0: d*v + c1*v
-// d = dg[el] when dg != nullptr (mask values, global memory), else [hth && t < t_in].
+//   KIND 1: dc*v + c2*Ldr_T(Ldr v) ; KIND 2: dc*v + c2*Lu v ; KIND 0: dc*v
+// dc = diagonal coefficient of the own elements (H^T H or mask value, plus the rho/2 terms), see lds_diag.
 // Returns sum_k v_k * (A v)_k of the own elements.  Uses ctx.Q as scratch; contains a barrier for KIND 1.
 // Callers separate successive calls by barriers.
 template <int TPG, bool BAND, int KIND>
-__device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND>& c, const float (&v)[TPG], float (&av)[TPG], const float* dg, int hth,
-                                           int t_in, float c1, float c2) {
+__device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND>& c, const float (&v)[TPG], float (&av)[TPG], const float (&dc)[TPG],
+                                           float c2) {
     float l[TPG];
 #pragma unroll
     for (int k = 0; k < TPG; ++k) l[k] = 0.f;
@@ -282,12 +303,20 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND>& c, const flo
     float part = 0.f;
 #pragma unroll
     for (int k = 0; k < TPG; ++k) {
-        float d = 0.f;
-        if (KIND != 2) d = dg ? (c.active ? dg[c.gl(k)] : 0.f) : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
-        av[k] = d * v[k] + c1 * v[k] + c2 * l[k];
+        av[k] = (KIND == 0) ? dc[k] * v[k] : dc[k] * v[k] + c2 * l[k];
         part += v[k] * av[k];
     }
     return part;
+}
+// diagonal coefficient d + c1 of the own elements: d = dg[el] when dg != nullptr (mask values, global
+// memory), else [hth && t < t_in]   (ADMM.py:371-379: H^T H x resp. mask * x; ADMM.py:381-399: none)
+template <int TPG, bool BAND>
+__device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND>& c, const float* dg, int hth, int t_in, float c1, float (&dc)[TPG]) {
+#pragma unroll
+    for (int k = 0; k < TPG; ++k) {
+        const float d = dg ? (c.active ? dg[c.gl(k)] : 0.f) : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
+        dc[k] = d + c1;
+    }
 }
 
 // CG_solver (ADMM.py:329-368) for one sample.  x, r of the own elements live in registers, the direction
@@ -298,10 +327,12 @@ template <int TPG, bool BAND, int KIND>
 __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
                       int hth, int t_in, float c1, float c2, int max_cg, double tol, float* ah, float* bh, int Bp,
                       int* nonfinite) {
-    float r[TPG], pv[TPG], av[TPG];
+    float r[TPG], pv[TPG], av[TPG], dc[TPG];
     c.put(c.P, x);
     __syncthreads();
-    (void)lds_apply<TPG, BAND, KIND>(c, x, av, dmask, hth, t_in, c1, c2);
+    lds_diag<TPG, BAND>(c, dmask, hth, t_in, c1, dc);
+    (void)lds_apply<TPG, BAND, KIND>(c, x, av, dc, c2);
+    if (dmask != nullptr) lds_diag<TPG, BAND>(c, nullptr, hth, t_in, c1, dc);     // quirk Q2: iterations use [t < t_in]
     float part = 0.f;
 #pragma unroll
     for (int k = 0; k < TPG; ++k) {
@@ -314,7 +345,7 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, 
     int iters = -1;
     for (int it = 0; it < max_cg; ++it) {
         __syncthreads();                 // p complete in LDS
-        part = lds_apply<TPG, BAND, KIND>(c, pv, av, nullptr, hth, t_in, c1, c2);
+        part = lds_apply<TPG, BAND, KIND>(c, pv, av, dc, c2);
         const float pAp = (float)br.sum(part);   // barrier: every gather from P/Q of this iteration is done
         const float alpha = rr / pAp;
         part = 0.f;

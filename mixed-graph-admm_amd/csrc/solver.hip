@@ -837,10 +837,12 @@ struct Engine : EngineBase {
         if (!std::is_same<S, float>::value) return MGADMM_OK;
         const int tpgs[] = {1, 2, 3, 4, 6, 8, 12};
         int best = 0;
+        const char* force = getenv("MGADMM_LDS_TPG");      // tests / experiments: force one time-group width
         for (int tpg : tpgs) {
             if (T % tpg) continue;
             const int G = T / tpg;
             if ((long)N * G > 1024) continue;
+            if (force && atoi(force) != tpg) continue;
             if (!best) best = tpg;        // smallest TPG = most threads
         }
         if (!best) return MGADMM_OK;
@@ -854,7 +856,7 @@ struct Engine : EngineBase {
         lds.off_en_u = off; off += 2 * nu;
         lds.off_en_d = off; off += 2 * nd;
         lds.off_en_t = off; off += 2 * nt;
-        off += 2;                      // one padding entry: the gather loop reads one entry ahead
+        off += 6;                      // three padding entries: the gather loop reads up to three entries ahead
         lds.csr_ints = off;
         // LDS row stride: T padded to an odd number of 16-byte slots (rows then start on every bank group);
         // fall back to the unpadded stride when the padded vectors do not fit

@@ -317,6 +317,28 @@ def test_full_solves_f32_kernels_vs_reference_f64(g4_meta, g4_solves, path):
     assert n >= 30
 
 
+@pytest.mark.parametrize("tpg", [2, 3, 4, 6, 8, 12])
+def test_lds_kernel_every_time_group_width(g4_meta, g4_solves, tpg, monkeypatch):
+    """The fused LDS kernel is instantiated per time-group width TPG (time steps per thread; the plan picks the
+    smallest that fits 1024 threads: 1 for the N = 30 fixtures, 8 for PEMS04).  Force each width on the
+    golden solves -- kNN (gathers with aligned windows + edge groups), line and skip-3 (band stencils),
+    all ablations, prediction and mask mode."""
+    from mgadmm import _lib
+    monkeypatch.setenv("MGADMM_LDS_TPG", str(tpg))
+    n = 0
+    for key in all_keys(g4_solves, "f64"):
+        mode, abl, task, tag, iters = key.split("-")
+        if int(iters) != 5:
+            continue
+        blk, x, zu, zd, phi = run_case(g4_meta, g4_solves, key, torch.float32, "lds")
+        assert _lib.lib.mgadmm_solver_path(blk._solvers[(1, torch.float32)][0], 1) == _lib.PATH_LDS
+        G = lambda f: g4_solves[f"{key}/{f}"]
+        check_solve(blk, key, G, abl, x, F32_X_TOL, F32_HIST_RTOL, 1)
+        blk.close()
+        n += 1
+    assert n >= 12
+
+
 def test_full_solves_f32_inputs(g4_meta, g4_solves):
     n = 0
     for key in all_keys(g4_solves, "f32"):
