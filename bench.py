@@ -227,8 +227,10 @@ def main():
         pr = blk.prof_end() if prof else None
         return x, pr
 
-    # warm-up (untimed): creates the solver workspace, pages kernels in
+    # warm-up (untimed): creates the solver workspace and the HIP event pool, pages kernels in
     run(max(1, args.warmup), False)
+    if not args.no_prof:
+        run(1, True)                        # the event pool of mgadmm_prof_begin is created on first use
     barrier()
     t0 = time.perf_counter()
     x, prof = run(args.steps, not args.no_prof)

@@ -303,7 +303,7 @@ struct Engine : EngineBase {
         MG_HIP(hipSetDevice(g->device));
         if (prof_ev.empty()) {
             prof_ev.resize(2 * PROF_POOL);
-            for (auto& e : prof_ev) MG_HIP(hipEventCreate(&e));
+            for (auto& e : prof_ev) MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));   // timing only: no system-scope cache flush per record
             prof_tag.resize(PROF_POOL);
         }
         prof_used = 0;
@@ -538,9 +538,9 @@ struct Engine : EngineBase {
             const int* live = k == 0 ? nullptr : d_nact + (k - 1);
             MG_TRY(lhs_apply(q, d, pp, nullptr, Ap, live));                  // Ap = A p (no mask: quirk Q2)
             MG_TRY((reduce<1>(q, FinCgAlpha<S>{c, k, q.Bp}, live)));
-            MG_TRY(rows<EpiCgUpdate>(q, op_none(), pp, live, 1, 6, (const S*)d_alpha, xout, r, (const S*)Ap));
+            MG_TRY(rows<EpiCgUpdate>(q, op_none(), Ap, live, 1, 3, (const S*)d_alpha, r));                 // r -= alpha Ap, r.r
             MG_TRY((reduce<1>(q, FinCgBeta<S>{c, k, q.Bp, p.cg_tol}, live)));
-            MG_TRY(rows<EpiPUpdate>(q, op_none(), r, live, 1, 3, (const S*)d_beta, pp));
+            MG_TRY(rows<EpiPUpdate>(q, op_none(), r, live, 1, 5, (const S*)d_alpha, (const S*)d_beta, xout, pp));   // x += alpha p, p = r + beta p
             MG_HIP(hipMemcpyAsync(h_nact + k, d_nact + k, sizeof(int), hipMemcpyDeviceToHost, st));
             MG_HIP(hipEventRecord(ev_ring[k % (LAG + 1)], st));
             if (k >= LAG) {

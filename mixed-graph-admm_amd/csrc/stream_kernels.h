@@ -550,51 +550,60 @@ struct EpiCgInit {
     }
 };
 
-// x += alpha p ; r -= alpha Ap ; acc0 += r.r     (ADMM.py:352-355).  Gathered vector = p.
+// CG vector updates (ADMM.py:352-366), split so that p is read once per iteration:
+//   EpiCgUpdate : r -= alpha Ap ; sum r^2                    (in = Ap; 12 B/element)
+//   EpiPUpdate  : x += alpha p ; p = r + beta p               (in = r;  20 B/element)
+// x += alpha p is the reference's ADMM.py:352 moved behind the beta reduction -- same operands, same
+// arithmetic, bitwise the same x.  Both kernels of iteration k are guarded by n_active[k-1] ("some sample
+// was active when iteration k started"), so the last x update of a sample that converges in iteration k
+// still happens; frozen samples have alpha = beta = 0.
 template <typename S, int VEC>
 struct EpiCgUpdate {
     static constexpr bool ELEMENTWISE = true;   // never launched with a spatial operator
     static constexpr int NRED = 1;
     static constexpr bool HAS_PRE = false;
     const S* alpha;
-    S *x, *r;
-    const S* Ap;
+    S* r;
     S a[VEC];
     __device__ void begin(int col0) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) a[v] = alpha[col0 + v];
     }
-    __device__ void row(int, size_t off, const Vec<S, VEC>& pv, const Vec<S, VEC>&, S (*acc)[VEC]) {
-        Vec<S, VEC> xv = ldv<S, VEC>(x + off), rv = ldv<S, VEC>(r + off);
-        const Vec<S, VEC> av = ldv<S, VEC>(Ap + off);
+    __device__ void row(int, size_t off, const Vec<S, VEC>& av, const Vec<S, VEC>&, S (*acc)[VEC]) {
+        Vec<S, VEC> rv = ldv<S, VEC>(r + off);
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            xv.v[v] = xv.v[v] + a[v] * pv.v[v];
             rv.v[v] = rv.v[v] - a[v] * av.v[v];
             acc[0][v] += rv.v[v] * rv.v[v];
         }
-        stv<S, VEC>(x + off, xv);
         stv<S, VEC>(r + off, rv);
     }
 };
 
-// p = r + beta p     (ADMM.py:366).  Gathered vector = r.
 template <typename S, int VEC>
 struct EpiPUpdate {
     static constexpr bool ELEMENTWISE = true;   // never launched with a spatial operator
     static constexpr int NRED = 0;
     static constexpr bool HAS_PRE = false;
+    const S* alpha;
     const S* beta;
-    S* p;
-    S b[VEC];
+    S *x, *p;
+    S a[VEC], b[VEC];
     __device__ void begin(int col0) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) b[v] = beta[col0 + v];
+        for (int v = 0; v < VEC; ++v) {
+            a[v] = alpha[col0 + v];
+            b[v] = beta[col0 + v];
+        }
     }
     __device__ void row(int, size_t off, const Vec<S, VEC>& rv, const Vec<S, VEC>&, S (*)[VEC]) {
-        Vec<S, VEC> pv = ldv<S, VEC>(p + off);
+        Vec<S, VEC> pv = ldv<S, VEC>(p + off), xv = ldv<S, VEC>(x + off);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) pv.v[v] = rv.v[v] + b[v] * pv.v[v];
+        for (int v = 0; v < VEC; ++v) {
+            xv.v[v] = xv.v[v] + a[v] * pv.v[v];
+            pv.v[v] = rv.v[v] + b[v] * pv.v[v];
+        }
+        stv<S, VEC>(x + off, xv);
         stv<S, VEC>(p + off, pv);
     }
 };

@@ -1,0 +1,89 @@
+"""Turn the three rocprofv3 passes of one bench command into the committed summary + profiles/traffic.json.
+
+    python tools/make_profile_summary.py gpurun_out/profN profiles/r01/NAME.txt "<bench command>"
+
+expects  <dir>/stats  (--kernel-trace --stats), <dir>/fetch (--pmc FETCH_SIZE), <dir>/write (--pmc WRITE_SIZE):
+separate runs, as MI355X_MICROARCH.md prescribes.  gfx950 correction: FETCH_SIZE under-reports wide
+coalesced streaming reads by exactly 2x -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB.
+"""
+import collections, csv, glob, json, os, re, statistics as st, sys
+
+
+def short(n):
+    n = n.replace('void ', '')
+    m = re.search(r'(k_rows|k_tile)<(\w+), (\d+), (\w+)(?:<[^>]*>)?, (\d+)', n)
+    if m:
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)},GW{m.group(5)}>"
+    m = re.search(r'k_admm_lds<(\d+), (\w+)>', n)
+    if m:
+        return f"k_admm_lds<{m.group(1)},{m.group(2)}>"
+    return n.split('(')[0][:52]
+
+
+def durations(d):
+    dur = collections.defaultdict(list)
+    f = glob.glob(d + '/**/*kernel_trace.csv', recursive=True)[0]
+    for r in csv.DictReader(open(f)):
+        dur[short(r['Kernel_Name'])].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    return dur
+
+
+def counters(d, name):
+    out = collections.defaultdict(list)
+    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
+    for r in csv.DictReader(open(f)):
+        if r['Counter_Name'] == name:
+            out[short(r['Kernel_Name'])].append(float(r['Counter_Value']))
+    return out
+
+
+def live_mean(v):
+    m = max(v)
+    lv = [x for x in v if x > 0.5 * m] if m > 0 else v
+    return st.mean(lv), len(lv)
+
+
+def main():
+    d, out, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+    dur = durations(d + '/stats')
+    fetch, write = counters(d + '/fetch', 'FETCH_SIZE'), counters(d + '/write', 'WRITE_SIZE')
+    tot = sum(sum(v) for v in dur.values())
+    L = [f"# rocprofv3 --kernel-trace --stats -- {cmd}",
+         "# default cfg2 workload (N=307, B=4096: LDS-resident path, k_admm_lds) followed by the cfg3 roofline leg",
+         "# (N=10000, B=512: streaming path; spatial operators in the LDS-tiled k_tile, element-wise work in k_rows).",
+         f"{'kernel':52s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s}"]
+    for k in sorted(dur, key=lambda k: -sum(dur[k]))[:24]:
+        v = dur[k]
+        L.append(f"{k:52s} {len(v):6d} {st.mean(v):10.1f} {sum(v) / 1e3:10.2f} {100 * sum(v) / tot:6.1f}")
+    L += ["", "# PMC passes (separate runs): FETCH_SIZE / WRITE_SIZE in KB per dispatch, mean over LIVE dispatches (dispatches",
+          "# skipped by the converged-CG early exit are excluded: counter > 50% of the kernel's max).",
+          "# hbm_MB = (2*FETCH_SIZE + WRITE_SIZE) KB / 1e3   (gfx950: FETCH_SIZE under-reports 16 B/lane streaming reads by 2x)",
+          f"{'kernel':44s} {'n_live':>6s} {'FETCH_KB':>10s} {'WRITE_KB':>10s} {'hbm_MB':>10s} {'live_avg_us':>12s}"]
+    per = {}
+    for k in sorted(fetch, key=lambda k: -sum(dur.get(k, [0]))):
+        if not (k.startswith('k_rows') or k.startswith('k_tile') or k.startswith('k_admm')):
+            continue
+        f, n = live_mean(fetch[k])
+        w, _ = live_mean(write.get(k, [0]))
+        du, _ = live_mean(dur[k]) if k in dur else (0, 0)
+        per[k] = (2 * f + w) * 1024.0
+        L.append(f"{k:44s} {n:6d} {f:10.0f} {w:10.0f} {per[k] / 1e6:10.1f} {du:12.1f}")
+    open(out, 'w').write("\n".join(L) + "\n")
+    # SpMM-in-CG kernels of the cfg3 leg: EpiLhs (GW4/GW8) and EpiStore, weighted by live launch counts
+    spmm = [k for k in per if k.startswith('k_tile') and ('EpiLhs' in k or 'EpiStore' in k)]
+    wts = {k: live_mean(fetch[k])[1] for k in spmm}
+    tj = {"_source": f"{out}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of `{cmd}`; "
+                     "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE under-reports 16 B/lane streaming reads by 2x); "
+                     "mean over live dispatches"}
+    lds = [k for k in per if k.startswith('k_admm_lds')]
+    if lds:
+        tj["cfg2"] = {"kernel": lds[0], "hbm_bytes_per_launch": per[lds[0]]}
+    if spmm:
+        tj["cfg3"] = {"kernel": "SpMM in CG = " + ", ".join(f"{k} ({wts[k]})" for k in sorted(spmm)),
+                      "hbm_bytes_per_launch": sum(per[k] * wts[k] for k in spmm) / sum(wts.values()),
+                      "per_kernel": {k: per[k] for k in sorted(per) if not k.startswith('k_admm')}}
+    json.dump(tj, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(out))), 'traffic.json'), 'w'), indent=1)
+    print("\n".join(L))
+
+
+main()
