@@ -168,6 +168,24 @@ int mgadmm_cg(mgadmm_solver* s, int32_t which, const void* rhs, const void* x0, 
 int mgadmm_solve(mgadmm_solver* s, const void* y, const void* mask, int32_t mask_is_f32, int32_t B, void* x_out,
                  const mgadmm_state* state_out, mgadmm_history* hist, void* stream);
 
+/* ---- graph construction on the GPU; host buffers in and out, synchronous ------------------
+ * k_nearest_neighbors(n_nodes, edges, dists, k) (utils.py:183-204): the k+1 nearest nodes of every node by
+ * shortest-path distance over the directed edge list (self first), one truncated Dijkstra per node in networkx's
+ * own visiting order (ties in distance resolve as in the reference).
+ *   edges  int64 (n_edges, 2) row-major (from, to) as in graph_info['u_edges']; a repeated edge overwrites the length
+ *   dists  float64 (n_edges)  non-negative edge lengths
+ *   nn_out int32 (n_nodes, k+1) with -1 pads;  nd_out float32 (n_nodes, k+1) with +inf pads */
+int mgadmm_knn_graph(int32_t n_nodes, int64_t n_edges, const int64_t* edges, const double* dists, int32_t k,
+                     int32_t* nn_out, float* nd_out, int32_t device);
+/* undirected_graph_from_distance / directed_graph_from_distance (utils.py:206-258) from the (n_nodes, k1) tables
+ * connect_list (int64, column 0 = the node itself, -1 pads) and dist_list (float32, +inf pads).
+ *   u_sigma, d_sigma  <= 0 selects the reference default max(dmax/50, dmin*50); the values used are returned
+ *                     in sigmas_out[2] (may be NULL)
+ *   u_ew  float32 (n_nodes, k1-1) or NULL;  d_ew  float32 (n_nodes, k1) or NULL;  regularized as in the reference */
+int mgadmm_weight_tables(int32_t n_nodes, int32_t k1, const int64_t* connect_list, const float* dist_list,
+                         double u_sigma, double d_sigma, int32_t regularized, float* u_ew, float* d_ew,
+                         double* sigmas_out, int32_t device);
+
 /* Per-kernel HIP-event timing on the launch stream (used by bench.py for the roofline figure).
  * tag 0 = sparse-Laplacian SpMM inside CG (the dominant kernel), 1 = CG vector update,
  * 2 = other SpMM launches, 3 = everything else. */

@@ -56,12 +56,25 @@ class ADMM_algorithm():
       reorder         internal node order: False/0, 'rcm'/1, 'cluster'/2 (greedy cluster growth; enables the
                       LDS-tiled SpMM kernel) or 'auto' (cluster order for N >= 1024)
       record_cg_coeffs  keep alpha/beta of every CG iteration: True/False/'auto' (B <= 64)
+      graph_backend   where the kNN search and the weight tables are computed: 'host' (NumPy, like the
+                      reference's set-up code), 'gpu' (mgadmm.gpu_graph: HIP kernels) or 'auto' (gpu for
+                      N >= 2048, where the host search takes seconds to minutes)
     """
 
     def __init__(self, graph_info, ADMM_info, use_kNN=False, k=4, u_sigma=None, d_sigma=None, expand_time_dim=True,
                  ablation='None', t_in=12, T=24, use_line_graph=False, skip_connection=1, *, device=None,
                  compute_dtype=torch.float32, bug_compat=True, tables=None, reorder='auto', record_cg_coeffs='auto',
-                 path='auto'):
+                 path='auto', graph_backend='auto'):
+        if graph_backend not in ('auto', 'host', 'gpu'):
+            raise ValueError(f"graph_backend must be 'auto', 'host' or 'gpu', got {graph_backend!r}")
+        if graph_backend == 'auto':
+            graph_backend = 'gpu' if graph_info['n_nodes'] >= 2048 else 'host'
+        self.graph_backend = graph_backend
+        if graph_backend == 'gpu':
+            from . import gpu_graph as _g
+        else:
+            _g = _u
+        self._tables_mod = _g
         self.t_in = t_in
         self.T = T
         self.use_line_graph = use_line_graph
@@ -73,18 +86,18 @@ class ADMM_algorithm():
         if tables is not None:
             self.connect_list, self.dist_list = torch.as_tensor(tables[0]).to(torch.int64), torch.as_tensor(tables[1]).float()
         elif use_kNN:
-            self.connect_list, self.dist_list = _u.k_nearest_neighbors(self.n_nodes, self.u_edges, self.u_dists, k)
+            self.connect_list, self.dist_list = _g.k_nearest_neighbors(self.n_nodes, self.u_edges, self.u_dists, k)
             self.connect_list = self.connect_list.to(torch.int64)
         else:
             self.connect_list, self.dist_list = _u.connect_list(self.n_nodes, self.u_edges, self.u_dists)
 
         assert ablation in ['None', 'DGTV', 'DGLR', 'UT'], "ablation should be in ['None', 'DGTV', 'DGLR', 'UT']"
         self.ablation = ablation
-        self.u_ew = _u.undirected_graph_from_distance(self.connect_list, self.dist_list, u_sigma=u_sigma)
+        self.u_ew = _g.undirected_graph_from_distance(self.connect_list, self.dist_list, u_sigma=u_sigma)
         if expand_time_dim:
             self.u_ew = _u.expand_time_dimension(self.u_ew, T)
         if not use_line_graph:
-            self.d_ew = _u.directed_graph_from_distance(self.connect_list, self.dist_list, d_sigma=d_sigma)
+            self.d_ew = _g.directed_graph_from_distance(self.connect_list, self.dist_list, d_sigma=d_sigma)
             if expand_time_dim:
                 self.d_ew = _u.expand_time_dimension(self.d_ew, T - 1)
         else:
@@ -134,7 +147,7 @@ class ADMM_algorithm():
         else:
             self.use_line_graph = False
             self.d_ew = _u.expand_time_dimension(
-                _u.directed_graph_from_distance(self.connect_list, self.dist_list, d_sigma=None), self.T - 1)
+                self._tables_mod.directed_graph_from_distance(self.connect_list, self.dist_list, d_sigma=None), self.T - 1)
         assert ablation in ['None', 'DGTV', 'DGLR', 'UT']
         self.ablation = ablation
         self._reset_history()

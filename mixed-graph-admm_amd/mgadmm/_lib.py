@@ -89,6 +89,9 @@ SYMBOLS = {
     "mgadmm_initial_interpolation": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp]),
     "mgadmm_cg": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _i32p, _f64p, _f64p, C.c_int32, _vp]),
     "mgadmm_solve": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, _vp, C.POINTER(State), C.POINTER(History), _vp]),
+    "mgadmm_knn_graph": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_int64), _f64p, C.c_int32, _i32p, _f32p, C.c_int32]),
+    "mgadmm_weight_tables": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int64), _f32p, C.c_double, C.c_double, C.c_int32,
+                                       _f32p, _f32p, _f64p, C.c_int32]),
     "mgadmm_prof_begin": (C.c_int, [_vp]),
     "mgadmm_prof_end": (C.c_int, [_vp, C.POINTER(C.c_int64), _f64p, _f64p]),
 }

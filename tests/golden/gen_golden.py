@@ -349,10 +349,19 @@ def g6_kats():
 
 
 def main():
+    only = set(sys.argv[1:])            # e.g. `gen_golden.py g1` regenerates the table fixtures only
     e12, d12 = make_graph(12, 3, seed=0, lo=1.0, hi=10.0, ring=True)
     e30, d30 = make_graph(30, 8, seed=1, lo=3.0, hi=600.0, ring=False)
     g1_tables("small", 12, e12, d12, k=3, sigma=5.0)
     g1_tables("pems", 30, e30, d30, k=4, sigma=50.0)
+    # integer edge lengths: many equal shortest-path distances, pins networkx's tie order (heap push counter,
+    # adjacency insertion order) for the truncated searches of the build; and a larger sparse road-like graph
+    e60, d60 = make_graph(60, 25, seed=2, lo=1.0, hi=4.0, ring=True)
+    g1_tables("ties", 60, e60, np.floor(d60), k=5, sigma=2.0)
+    e400, d400 = make_graph(400, 60, seed=3, lo=3.0, hi=2900.0, ring=False)
+    g1_tables("road400", 400, e400, d400, k=4, sigma=50.0)
+    if only == {"g1"}:
+        return
     g2_ops(12, e12, d12, k=3, sigma=5.0)
     g3_cg(12, e12, d12, k=3, sigma=5.0)
     g4_solves(30, e30, d30, k=4, sigma=50.0)

@@ -20,7 +20,7 @@ def test_connect_list_kat():
     assert dl.tolist() == [[0, 1, inf], [0, 1, 2], [0, 2, 3], [0, 3, inf]]
 
 
-@pytest.mark.parametrize("name", ["small", "pems"])
+@pytest.mark.parametrize("name", ["small", "pems", "ties", "road400"])
 def test_tables_match_reference(name):
     g = load_golden(f"g1_tables_{name}.npz")
     n, k, sigma = int(g["n"]), int(g["k"]), float(g["sigma"])

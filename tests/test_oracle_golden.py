@@ -88,7 +88,7 @@ def test_kat_initial_interpolation():
 
 
 # ---------------------------------------------------------------- G1 tables
-@pytest.mark.parametrize("name", ["small", "pems"])
+@pytest.mark.parametrize("name", ["small", "pems", "ties", "road400"])
 def test_g1_tables(name):
     g = load_golden(f"g1_tables_{name}.npz")
     n, k, sigma = int(g["n"]), int(g["k"]), float(g["sigma"])
