@@ -186,6 +186,25 @@ int mgadmm_weight_tables(int32_t n_nodes, int32_t k1, const int64_t* connect_lis
                          double u_sigma, double d_sigma, int32_t regularized, float* u_ew, float* d_ew,
                          double* sigmas_out, int32_t device);
 
+/* ---- data front end on the GPU: TrafficDataset (utils.py:54-134) ---------------------------
+ * `series` is the (n_steps, n_cols) row-major device array data[t, node*C + c] of dtype MGADMM_F32/F64.
+ * Per-column statistics over time (device outputs of n_cols elements in the series dtype, any may be NULL):
+ * min / max (utils.py:87-88), mean and the unbiased standard deviation of torch.std (utils.py:83-84).
+ * Fixed-order reductions (bitwise repeatable).  Asynchronous on `stream`. */
+int mgadmm_series_stats(const void* series, int64_t n_steps, int32_t n_cols, int32_t dtype, void* o_min, void* o_max,
+                        void* o_mean, void* o_std, void* stream);
+/* In place.  inverse == 0: series = (series - shift[col]) / s[col]; inverse != 0 (recover_data, utils.py:110-118):
+ * series = series * s[col] + shift[col]; s = scale - scale_lo when scale_lo != NULL ('normalize': shift = min,
+ * scale = max, scale_lo = min), else s = scale ('standardize': shift = mean, scale = std).  Asynchronous. */
+int mgadmm_series_affine(void* series, int64_t n_steps, int32_t n_cols, int32_t dtype, const void* shift, const void* scale,
+                         const void* scale_lo, int32_t inverse, void* stream);
+/* Sliding windows for a batch of start indices (get_predict_data / get_interpolated_data, utils.py:121-134):
+ * out[b, t, col] = series[starts[b] + t, col] * (mask ? mask[t, col] : 1), t < win.  starts: device int64[B];
+ * mask: device float32 (win, n_cols) or NULL; out: device (B, win, n_cols) of the series dtype.
+ * Synchronous (reports a start index outside [0, n_steps - win]). */
+int mgadmm_gather_windows(const void* series, int64_t n_steps, int32_t n_cols, int32_t dtype, const int64_t* starts, int32_t B,
+                          int32_t win, const float* mask, void* out, void* stream);
+
 /* Per-kernel HIP-event timing on the launch stream (used by bench.py for the roofline figure).
  * tag 0 = sparse-Laplacian SpMM inside CG (the dominant kernel), 1 = CG vector update,
  * 2 = other SpMM launches, 3 = everything else. */

@@ -13,5 +13,6 @@ from .ADMM import ADMM_algorithm, initial_guess, initial_interpolation  # noqa: 
 from .CG_script import conjugate_gradient  # noqa: F401
 from .dist import shard_bounds, sharded_solve  # noqa: F401
 from . import gpu_graph  # noqa: F401
+from .dataset import TrafficDataset  # noqa: F401
 
 __version__ = _lib.version()

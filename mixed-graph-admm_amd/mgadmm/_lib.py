@@ -92,6 +92,9 @@ SYMBOLS = {
     "mgadmm_knn_graph": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_int64), _f64p, C.c_int32, _i32p, _f32p, C.c_int32]),
     "mgadmm_weight_tables": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int64), _f32p, C.c_double, C.c_double, C.c_int32,
                                        _f32p, _f32p, _f64p, C.c_int32]),
+    "mgadmm_series_stats": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "mgadmm_series_affine": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp]),
+    "mgadmm_gather_windows": (C.c_int, [_vp, C.c_int64, C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp, _vp]),
     "mgadmm_prof_begin": (C.c_int, [_vp]),
     "mgadmm_prof_end": (C.c_int, [_vp, C.POINTER(C.c_int64), _f64p, _f64p]),
 }

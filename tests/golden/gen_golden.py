@@ -17,6 +17,7 @@ Fixture groups:
   g4_solve_*    full combined_loop runs + history              (ADMM.py:511-648)
   g5_batched    8 single-sample solves stacked                 (batched-parity definition, Q6)
   g6_kats       small literal known-answer vectors             (notebook / __main__ KATs)
+  g7_dataset    TrafficDataset on synthetic files               (utils.py:54-134)
 """
 import contextlib
 import io
@@ -348,8 +349,53 @@ def g6_kats():
     np.savez_compressed(os.path.join(OUT, "g6_kats.npz"), **out)
 
 
+def g7_dataset():
+    """TrafficDataset (utils.py:54-134) on synthetic files: distance csv with non-contiguous sensor ids, id file,
+    npz series with 3 features (the class keeps the first).  Inputs and outputs are stored; the test re-creates
+    the files from the stored arrays."""
+    import tempfile
+    rng = np.random.default_rng(5)
+    n, steps = 12, 80
+    ids = 100 + 7 * np.arange(n)
+    e, d = make_graph(n, 4, seed=4, lo=3.0, hi=600.0, ring=False)
+    t = np.arange(steps)[:, None]
+    base = rng.uniform(50, 400, size=(1, n))
+    series = base + 0.3 * base * np.sin(2 * np.pi * (t + rng.integers(0, 20, size=(1, n))) / 40.0) + 5 * rng.standard_normal((steps, n))
+    data = np.stack([series, rng.standard_normal((steps, n)), rng.standard_normal((steps, n))], -1)     # (T, N, 3) float64
+    out = dict(ids=ids, csv_from=ids[e[:, 0]], csv_to=ids[e[:, 1]], csv_cost=d, data=data)
+    with tempfile.TemporaryDirectory() as td:
+        pd.DataFrame({"from": out["csv_from"], "to": out["csv_to"], "cost": d}).to_csv(os.path.join(td, "dist.csv"), index=False)
+        pd.DataFrame({"from": e[:, 0], "to": e[:, 1], "cost": d}).to_csv(os.path.join(td, "dist_plain.csv"), index=False)
+        np.savetxt(os.path.join(td, "ids.txt"), ids, fmt="%d")
+        np.savez(os.path.join(td, "series.npz"), data=data)
+        for tr in (None, "standardize", "normalize"):
+            ds = quiet(ref_utils.TrafficDataset, td, "series.npz", "dist.csv", id_file="ids.txt", transform=tr)
+            tag = str(tr)
+            out[f"{tag}/data"] = ds.data.numpy()
+            if tr == "standardize":
+                out[f"{tag}/mean"], out[f"{tag}/std"] = ds.data_mean.numpy(), ds.data_std.numpy()
+            if tr == "normalize":
+                out[f"{tag}/max"], out[f"{tag}/min"] = ds.data_max.numpy(), ds.data_min.numpy()
+            x, y = ds.get_predict_data(5)
+            out[f"{tag}/pred_x"], out[f"{tag}/pred_y"] = x.numpy(), y.numpy()
+            ix, iy, im = ds.get_interpolated_data(7, 0.4)
+            out[f"{tag}/int_x"], out[f"{tag}/int_y"], out[f"{tag}/int_mask"] = ix.numpy(), iy.numpy(), im.numpy()
+            out[f"{tag}/recovered"] = ds.recover_data(x).numpy()
+            if tr is None:
+                gi = ds.graph_info
+                out["gi_n_nodes"], out["gi_n_edges"] = gi["n_nodes"], gi["n_edges"]
+                out["gi_u_edges"], out["gi_u_dist"] = gi["u_edges"].numpy(), gi["u_dist"].numpy()
+        ds = quiet(ref_utils.TrafficDataset, td, "series.npz", "dist_plain.csv")
+        out["plain_n_nodes"] = ds.graph_info["n_nodes"]
+        out["plain_u_edges"] = ds.graph_info["u_edges"].numpy()
+    np.savez_compressed(os.path.join(OUT, "g7_dataset.npz"), **out)
+
+
 def main():
-    only = set(sys.argv[1:])            # e.g. `gen_golden.py g1` regenerates the table fixtures only
+    only = set(sys.argv[1:])
+    if only == {"g7"}:
+        g7_dataset()
+        return            # e.g. `gen_golden.py g1` regenerates the table fixtures only
     e12, d12 = make_graph(12, 3, seed=0, lo=1.0, hi=10.0, ring=True)
     e30, d30 = make_graph(30, 8, seed=1, lo=3.0, hi=600.0, ring=False)
     g1_tables("small", 12, e12, d12, k=3, sigma=5.0)
@@ -367,6 +413,7 @@ def main():
     g4_solves(30, e30, d30, k=4, sigma=50.0)
     g5_batched(30, e30, d30, k=4, sigma=50.0)
     g6_kats()
+    g7_dataset()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))
