@@ -156,7 +156,7 @@ def roofline_from_prof(prof, workload, path="stream", elems=0, cg=None):
         kernel = "k_admm_lds<TPG> (LDS-resident fused ADMM iteration: 3 CG solves + prox + duals + history per launch)"
     else:
         bytes_per = p0["bytes"] / p0["count"]
-        kernel = "k_rows<SpMM in CG> (sparse mixed-graph Laplacian, batch-innermost)"
+        kernel = "k_tile / k_rows <SpMM in CG> (sparse mixed-graph Laplacian, batch-innermost; LDS-tiled on cluster-ordered graphs)"
     ach = bytes_per / (avg_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(workload), "launches": p0["count"],
