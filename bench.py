@@ -61,7 +61,13 @@ def pems_like_graph(n, n_edges, seed=0):
 
 def build_problem(workload):
     import mgadmm
-    if workload == "cfg2":
+    if workload == "cfg1":          # the reference's own CPU-runnable case (parity test, not a bench line)
+        n, B = 170, 1
+        ue, ud = pems_like_graph(n, 295, seed=0)
+        cl, dl = mgadmm.utils.k_nearest_neighbors(n, ue, ud, 4)
+        cl = cl.to(torch.int64)
+        desc = "PEMS08-shaped synthetic graph N=170 (path+chords, 295 edges), kNN k=4, T=24, t_in=12"
+    elif workload == "cfg2":
         n, B = 307, 4096
         ue, ud = pems_like_graph(n, 340, seed=0)
         cl, dl = mgadmm.utils.k_nearest_neighbors(n, ue, ud, 4)

@@ -159,3 +159,33 @@ def test_cfg5_fp32_vs_fp64_tolerance_sweep():
         np.testing.assert_allclose(d, ref[2], rtol=1e-3)
         for a, r in ((ix, ref[3]), (izu, ref[4]), (izd, ref[5])):
             assert int((a - r).abs().max()) <= 1, name
+
+
+def test_cfg1_pems08_size_full_run_vs_oracle():
+    """BASELINE config 1 (PEMS08-shaped graph N = 170, B = 1, y = 300*rand float64, 50 iterations) -- the one
+    configuration the CPU oracle runs in full: float64 HIP kernels reproduce it to 1e-10 with identical CG counts,
+    the float32 paths (LDS-resident kernel at TPG = 4: 170 x 6 = 1020 threads; streaming) to the cfg5 tolerances."""
+    import mgadmm
+    from oracle import admm_oracle as orc
+    b = _bench()
+    n, B, cl, dl, info, _ = b.build_problem("cfg1")
+    y = 300 * torch.rand(1, 12, n, 1, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    blk0 = mgadmm.ADMM_algorithm({"n_nodes": n}, info, use_kNN=True, k=4, u_sigma=50, d_sigma=50, tables=(cl, dl))
+    o = orc.OracleADMM(cl.numpy(), blk0.u_ew[0].numpy(), blk0.d_ew[0].numpy(), info, mode="knn", t_in=12, T=24)
+    blk0.close()
+    xo = o.combined_loop(y.numpy(), n_iters=50)
+    ho = o.hist
+    for name, kw, xtol, htol, slack in (("f64", dict(compute_dtype=torch.float64), 1e-10, 1e-8, 0),
+                                        ("lds", dict(path="lds"), 1e-5, 1e-3, 1), ("stream", dict(path="stream"), 1e-5, 1e-3, 1)):
+        blk = mgadmm.ADMM_algorithm({"n_nodes": n}, info, use_kNN=True, k=4, u_sigma=50, d_sigma=50, tables=(cl, dl), **kw)
+        blk.max_ADMM_iter = 50
+        blk.check_stop = False
+        x = blk.combined_loop(y, print_info=False)
+        assert x.dtype == torch.float64 and float((x - torch.from_numpy(xo)).norm() / np.linalg.norm(xo)) < xtol, name
+        floor = (1e-8 if htol >= 1e-4 else 1e-14) * float(np.linalg.norm(xo))
+        np.testing.assert_allclose(np.array(blk.p_res_list), np.array(ho.p_res_list), rtol=htol, atol=floor)
+        np.testing.assert_allclose(np.array(blk.d_res_list), np.array(ho.d_res_list), rtol=htol, atol=floor)
+        for nm in ("CG_iter_x", "CG_iter_zu", "CG_iter_zd"):
+            got = np.array([int(v) for v in getattr(blk, nm)])
+            assert np.abs(got - np.array(getattr(ho, nm)).reshape(got.shape)).max() <= slack, (name, nm)
+        blk.close()
