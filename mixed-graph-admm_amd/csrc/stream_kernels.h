@@ -24,6 +24,11 @@ template <typename S, int V>
 __device__ __forceinline__ Vec<S, V> ldv(const S* p) {
     return *reinterpret_cast<const Vec<S, V>*>(p);
 }
+// plain vector store (LDS staging in k_tile)
+template <typename S, int V>
+__device__ __forceinline__ void stl(S* p, const Vec<S, V>& x) {
+    *reinterpret_cast<Vec<S, V>*>(p) = x;
+}
 // Every vector the streaming kernels write is consumed by a LATER kernel, long after it has left the 4 MiB
 // L2 of its XCD: non-temporal stores keep the output from evicting the input slices the time-shifted
 // operators and the tile halos re-read (measured on cfg3: SpMM in CG 4.78 -> 4.84 TB/s, vector updates
@@ -393,13 +398,13 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
 #pragma unroll
             for (int k = 0; k < TILE_HPW; ++k) {
                 const int hr = __builtin_amdgcn_readlane(hrow, k);
-                if (hr >= 0) stv<S, VEC>(hdst + (size_t)(wave + 4 * k) * W, hv[k]);
+                if (hr >= 0) stl<S, VEC>(hdst + (size_t)(wave + 4 * k) * W, hv[k]);
             }
         }
         if (shift == 0) {                               // Lu gathers from the slice of this step
 #pragma unroll
             for (int j = 0; j < TILE_MAXR; ++j)
-                if (j < m) stv<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
+                if (j < m) stl<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
         }
         __syncthreads();                                // halo (and for Lu the own rows) visible
         // 2. gathers + epilogue, row by row: every regular neighbour is a conflict-free LDS row read
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
         if (shift != 0) {
 #pragma unroll
             for (int j = 0; j < TILE_MAXR; ++j)
-                if (j < m) stv<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
+                if (j < m) stl<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
         }
 #pragma unroll
         for (int j = 0; j < TILE_MAXR; ++j) own[j] = ownn[j];
