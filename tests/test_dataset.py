@@ -119,3 +119,17 @@ def test_windows_feed_the_solver(tmp_path):
         x1 = blk.combined_loop(ds.get_predict_data(s)[1].unsqueeze(0), print_info=False)
         assert float((xb[b] - x1[0]).norm() / x1[0].norm()) < 1e-6
     blk.close()
+
+
+@pytest.mark.gpu
+def test_example_workflow_runs(monkeypatch):
+    """examples/pems_workflow.py: files -> GPU-resident data set -> kNN graph -> batched prediction and interpolation."""
+    import importlib.util
+    import sys as _sys
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("pems_workflow", os.path.join(ROOT, "examples", "pems_workflow.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(_sys, "argv", ["pems_workflow.py", "--nodes", "60", "--steps", "200", "--batch", "8", "--iters", "5"])
+    mae_pred, mae_int = mod.main()
+    assert np.isfinite(mae_pred) and np.isfinite(mae_int)
