@@ -127,12 +127,11 @@ struct Engine : EngineBase {
     bool make_tile_geom(const Geom& q, TileGeom& tg) const {
         if (!use_tile || g->reorder < 2 || g->mode != MGADMM_TEMPORAL_SPATIAL) return false;
         tg.T = T; tg.N = N; tg.B = q.B; tg.Bp = q.Bp; tg.VEC = q.VEC; tg.CH = q.CH;
-        // tile size: 20 rows measured best on the 10k-node graph (12..24 are within 2 %); smaller tiles when
-        // the problem would otherwise not fill the machine (>= 512 workgroups wanted)
-        const int rmax = 4 * TILE_MAXR;
-        int best = 20;
-        while (best > 8 && (long)q.CH * ((N + best - 1) / best) < 512) best -= 4;
-        if (const char* e = getenv("MGADMM_TILE_R")) { int rr = atoi(e); if (rr >= 4 && rr <= rmax && rr % 4 == 0) best = rr; }
+        // tile size: 20 rows (5 per wave) measured best on the 10k-node graph (12..24 are within 2 %); 8-row
+        // tiles (2 per wave) when the problem would otherwise not fill the machine (>= 512 workgroups wanted).
+        // The rows per wave are a template parameter of k_tile, so only these two sizes exist.
+        int best = ((long)q.CH * ((N + 19) / 20) < 512) ? 8 : 20;
+        if (const char* e = getenv("MGADMM_TILE_R")) { int rr = atoi(e); if (rr == 8 || rr == 20) best = rr; }
         tg.R = best;
         tg.NTILE = (N + best - 1) / best;
         tg.TPX = (tg.NTILE + 7) / 8;
@@ -362,7 +361,12 @@ struct Engine : EngineBase {
 
     template <int VEC, class Epi, int TGW>
     int launch_tile(const TileGeom& tg, const OpDesc& op, const TileMeta& tmv, const S* in, const Epi& epi, const int* live) {
-        auto fn = k_tile<S, VEC, Epi, TGW>;
+        return tg.R == 20 ? launch_tile2<VEC, Epi, TGW, 5>(tg, op, tmv, in, epi, live)
+                          : launch_tile2<VEC, Epi, TGW, 2>(tg, op, tmv, in, epi, live);
+    }
+    template <int VEC, class Epi, int TGW, int MR>
+    int launch_tile2(const TileGeom& tg, const OpDesc& op, const TileMeta& tmv, const S* in, const Epi& epi, const int* live) {
+        auto fn = k_tile<S, VEC, Epi, TGW, MR>;
         static bool attr_set = false;
         if (!attr_set) {
             MG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));

@@ -302,15 +302,21 @@ struct TileMeta {
     const float* h_val;
 };
 
-template <typename S, int VEC, class Epi, int TILE_GW>
+// MR = rows per wave (tile = 4*MR rows), a compile-time constant: the row loops are straight-line code (the
+// LDS reads of one row overlap the FMAs of the previous one, no per-row branches) and the register arrays
+// hold exactly MR rows.  Rows past the end of a short last tile are clamped to the tile's last row: they
+// recompute and re-store that row (same inputs, same values) and are kept out of the dot products.
+template <typename S, int VEC, class Epi, int TILE_GW, int MR>
 __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* __restrict__ tl_col,
                                               const float* __restrict__ tl_w, const int* __restrict__ halo,
                                               const int* __restrict__ h_rowptr, const int* __restrict__ h_col,
                                               const float* __restrict__ h_val, const S* __restrict__ in, Epi epi_in,
                                               S* __restrict__ partials, const int* __restrict__ live) {
+    static_assert(MR * TILE_GW <= 64 && MR <= TILE_MAXR, "per-row metadata must fit the 64 lanes of a wave");
     extern __shared__ __align__(16) unsigned char tile_raw[];
     if (live != nullptr && *live == 0) return;
     constexpr int W = 64 * VEC;
+    constexpr int R = 4 * MR;
     S* tile = reinterpret_cast<S*>(tile_raw);          // [R + TILE_HMAX][W]: own-tile rows, then halo rows
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -320,26 +326,33 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
     const int r = q / g.CH;
     const int tidx = xcd * g.TPX + r;                  // consecutive tiles share an XCD (halo rows hit its L2)
     const int col0 = (chunk * 64 + lane) * VEC;
-    const int n0 = tidx * g.R;
-    const int n1 = (tidx < g.NTILE) ? min(g.N, n0 + g.R) : n0;
-    const int m = (n1 - n0 - wave + 3) / 4;            // rows of this wave: n0 + wave + 4*j, j < m
+    const bool tile_ok = tidx < g.NTILE;               // the grid is padded to 8 * TPX tiles
+    const int n0 = tile_ok ? tidx * R : 0;
+    const int nlast = tile_ok ? min(g.N, n0 + R) - 1 : 0;
+    int rowi[MR];                                      // global row of local row wave + 4*j (clamped in a short tile)
+    bool rowok[MR];
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+        rowok[j] = tile_ok && (n0 + wave + 4 * j <= nlast);
+        rowi[j] = min(n0 + wave + 4 * j, nlast);
+    }
 
     // wave-resident metadata: lane (j*TILE_GW + u) holds slot u of row j; lane j also holds the overflow
     // bounds of row j; lane k < TILE_HPW holds the global index of halo row (wave + 4*k) of this tile
     int mcol = 0, mw = 0, hs = 0, hc = 0, hrow = -1;
     {
         const int j = lane / TILE_GW, u = lane - j * TILE_GW;
-        if (j < m && j < TILE_MAXR) {
-            const int i = n0 + wave + 4 * j;
+        if (j < MR) {
+            const int i = min(n0 + wave + 4 * j, nlast);
             mcol = tl_col[(size_t)i * TILE_GW + u];
             mw = __float_as_int(tl_w[(size_t)i * TILE_GW + u]);
         }
-        if (lane < m) {
-            const int i = n0 + wave + 4 * lane;
+        if (lane < MR) {
+            const int i = min(n0 + wave + 4 * lane, nlast);
             hs = h_rowptr[i];
             hc = h_rowptr[i + 1] - hs;
         }
-        if (lane < TILE_HPW && tidx < g.NTILE) hrow = halo[(size_t)tidx * TILE_HMAX + wave + 4 * lane];
+        if (lane < TILE_HPW && tile_ok) hrow = halo[(size_t)tidx * TILE_HMAX + wave + 4 * lane];
     }
 
     Epi epi = epi_in;
@@ -351,67 +364,62 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[rr][v] = S(0);
 
-    const int shift = op.shift;
-    const S* trow = tile + lane * VEC;
-    S* hdst = tile + (size_t)g.R * W + lane * VEC;
-    auto step_t = [&](int sidx) { return shift > 0 ? g.T - 1 - sidx : sidx; };
-    // own rows of the first step; afterwards the own rows of step s+1 are requested while step s computes
-    Vec<S, VEC> own[TILE_MAXR];
-    {
-        const S* obase = in + (size_t)step_t(0) * g.N * g.Bp + col0;
-#pragma unroll
-        for (int j = 0; j < TILE_MAXR; ++j)
-            if (j < m) own[j] = ldv<S, VEC>(obase + (size_t)(n0 + wave + 4 * j) * g.Bp);
-    }
-    for (int step = 0; step < g.T; ++step) {
-        const int t = step_t(step);
-        const int ts = t + shift;
-        const bool tvalid = ts >= 0 && ts < g.T;
-        S selfc = S(1);
-        if (op.self_mode == SELF_LDR) selfc = (t >= 1) ? S(1) : S(0);
-        else if (op.self_mode == SELF_LDRT) selfc = (t > 0 || op.q1) ? S(1) : S(0);
-        const S* gbase = in + (size_t)(tvalid ? ts : t) * g.N * g.Bp + col0;
-        // 1. requests of this step, in the order they are needed: halo rows of the gathered slice, the
-        //    epilogue's operand rows, and the own rows of the NEXT step
-        Vec<S, VEC> hv[TILE_HPW];
-        if (tvalid) {
-#pragma unroll
-            for (int k = 0; k < TILE_HPW; ++k) {
-                const int hr = __builtin_amdgcn_readlane(hrow, k);
-                if (hr >= 0) hv[k] = ldv<S, VEC>(gbase + (size_t)hr * g.Bp);
-            }
-        }
-        Vec<S, VEC> pre[TILE_MAXR];
-        if constexpr (Epi::HAS_PRE) {
-#pragma unroll
-            for (int j = 0; j < TILE_MAXR; ++j)
-                if (j < m) pre[j] = epi.pre(((size_t)t * g.N + n0 + wave + 4 * j) * g.Bp + col0);
-        }
-        Vec<S, VEC> ownn[TILE_MAXR];
+    if (tile_ok) {
+        const int shift = op.shift;
+        const S* trow = tile + lane * VEC;
+        S* hdst = tile + (size_t)R * W + lane * VEC;
+        auto step_t = [&](int sidx) { return shift > 0 ? g.T - 1 - sidx : sidx; };
+        // own rows of the first step; afterwards the own rows of step s+1 are requested while step s computes
+        Vec<S, VEC> own[MR];
         {
-            const S* nbase = in + (size_t)step_t(min(step + 1, g.T - 1)) * g.N * g.Bp + col0;
+            const S* obase = in + (size_t)step_t(0) * g.N * g.Bp + col0;
 #pragma unroll
-            for (int j = 0; j < TILE_MAXR; ++j)
-                if (j < m) ownn[j] = ldv<S, VEC>(nbase + (size_t)(n0 + wave + 4 * j) * g.Bp);
+            for (int j = 0; j < MR; ++j) own[j] = ldv<S, VEC>(obase + (size_t)rowi[j] * g.Bp);
         }
-        if (tvalid) {
+        for (int step = 0; step < g.T; ++step) {
+            const int t = step_t(step);
+            const int ts = t + shift;
+            const bool tvalid = ts >= 0 && ts < g.T;
+            S selfc = S(1);
+            if (op.self_mode == SELF_LDR) selfc = (t >= 1) ? S(1) : S(0);
+            else if (op.self_mode == SELF_LDRT) selfc = (t > 0 || op.q1) ? S(1) : S(0);
+            const S* gbase = in + (size_t)(tvalid ? ts : t) * g.N * g.Bp + col0;
+            // 1. requests of this step, in the order they are needed: halo rows of the gathered slice, the
+            //    epilogue's operand rows, and the own rows of the NEXT step
+            Vec<S, VEC> hv[TILE_HPW];
+            if (tvalid) {
 #pragma unroll
-            for (int k = 0; k < TILE_HPW; ++k) {
-                const int hr = __builtin_amdgcn_readlane(hrow, k);
-                if (hr >= 0) stl<S, VEC>(hdst + (size_t)(wave + 4 * k) * W, hv[k]);
+                for (int k = 0; k < TILE_HPW; ++k) {
+                    const int hr = __builtin_amdgcn_readlane(hrow, k);
+                    if (hr >= 0) hv[k] = ldv<S, VEC>(gbase + (size_t)hr * g.Bp);
+                }
             }
-        }
-        if (shift == 0) {                               // Lu gathers from the slice of this step
+            Vec<S, VEC> pre[MR];
+            if constexpr (Epi::HAS_PRE) {
 #pragma unroll
-            for (int j = 0; j < TILE_MAXR; ++j)
-                if (j < m) stl<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
-        }
-        __syncthreads();                                // halo (and for Lu the own rows) visible
-        // 2. gathers + epilogue, row by row: every regular neighbour is a conflict-free LDS row read
+                for (int j = 0; j < MR; ++j) pre[j] = epi.pre(((size_t)t * g.N + rowi[j]) * g.Bp + col0);
+            }
+            Vec<S, VEC> ownn[MR];
+            {
+                const S* nbase = in + (size_t)step_t(min(step + 1, g.T - 1)) * g.N * g.Bp + col0;
 #pragma unroll
-        for (int j = 0; j < TILE_MAXR; ++j) {
-            if (j < m) {
-                const int i = n0 + wave + 4 * j;
+                for (int j = 0; j < MR; ++j) ownn[j] = ldv<S, VEC>(nbase + (size_t)rowi[j] * g.Bp);
+            }
+            if (tvalid) {
+#pragma unroll
+                for (int k = 0; k < TILE_HPW; ++k) {
+                    const int hr = __builtin_amdgcn_readlane(hrow, k);
+                    if (hr >= 0) stl<S, VEC>(hdst + (size_t)(wave + 4 * k) * W, hv[k]);
+                }
+            }
+            if (shift == 0) {                               // Lu gathers from the slice of this step
+#pragma unroll
+                for (int j = 0; j < MR; ++j) stl<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
+            }
+            __syncthreads();                                // halo (and for Lu the own rows) visible
+            // 2. gathers + epilogue, row by row: every regular neighbour is a conflict-free LDS row read
+#pragma unroll
+            for (int j = 0; j < MR; ++j) {
                 Vec<S, VEC> sum;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) sum.v[v] = S(0);
@@ -442,20 +450,35 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
                 Vec<S, VEC> l;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) l.v[v] = selfc * own[j].v[v] - sum.v[v];
-                const size_t off = ((size_t)t * g.N + i) * g.Bp + col0;
-                if constexpr (Epi::HAS_PRE) epi.row_pre(t, off, own[j], l, acc, pre[j]);
-                else epi.row(t, off, own[j], l, acc);
+                const size_t off = ((size_t)t * g.N + rowi[j]) * g.Bp + col0;
+                if constexpr (Epi::NRED > 0) {
+                    S keep[NR][VEC];
+#pragma unroll
+                    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                        for (int v = 0; v < VEC; ++v) keep[rr][v] = acc[rr][v];
+                    if constexpr (Epi::HAS_PRE) epi.row_pre(t, off, own[j], l, acc, pre[j]);
+                    else epi.row(t, off, own[j], l, acc);
+                    if (!rowok[j]) {                        // clamped duplicate of the tile's last row: not summed twice
+#pragma unroll
+                        for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) acc[rr][v] = keep[rr][v];
+                    }
+                } else {
+                    if constexpr (Epi::HAS_PRE) epi.row_pre(t, off, own[j], l, acc, pre[j]);
+                    else epi.row(t, off, own[j], l, acc);
+                }
             }
-        }
-        __syncthreads();                                // every gather of this step is done
-        // 3. this step's rows become the gathered slice of the next step
-        if (shift != 0) {
+            __syncthreads();                                // every gather of this step is done
+            // 3. this step's rows become the gathered slice of the next step
+            if (shift != 0) {
 #pragma unroll
-            for (int j = 0; j < TILE_MAXR; ++j)
-                if (j < m) stl<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
-        }
+                for (int j = 0; j < MR; ++j) stl<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
+            }
 #pragma unroll
-        for (int j = 0; j < TILE_MAXR; ++j) own[j] = ownn[j];
+            for (int j = 0; j < MR; ++j) own[j] = ownn[j];
+        }
     }
 
     if (Epi::NRED > 0) {
