@@ -55,6 +55,16 @@ def main():
     for k in sorted(dur, key=lambda k: -sum(dur[k]))[:24]:
         v = dur[k]
         L.append(f"{k:52s} {len(v):6d} {st.mean(v):10.1f} {sum(v) / 1e3:10.2f} {100 * sum(v) / tot:6.1f}")
+    mix = [k for k in dur if k.startswith('k_tile') and ('EpiLhs' in k or 'EpiStore' in k)]
+    if mix:
+        nl = sum(len(dur[k]) for k in mix)
+        L += ["", f"# SpMM inside CG on the cfg3 leg = {', '.join(sorted(mix))}: {nl} launches, average "
+                  f"{sum(sum(dur[k]) for k in mix) / nl:.1f} us (converged-CG no-op launches included, as in bench.py's",
+              "# roofline_cfg3.avg_launch_us, which times the same launch mix with HIP events)"]
+    lds = [k for k in dur if k.startswith('k_admm_lds')]
+    if lds:
+        L += [f"# {lds[0]}: average {st.mean(dur[lds[0]]):.1f} us over {len(dur[lds[0]])} launches (bench.py roofline.avg_launch_us; the first"
+              " launches of a solve run more CG iterations than the later ones)"]
     L += ["", "# PMC passes (separate runs): FETCH_SIZE / WRITE_SIZE in KB per dispatch, mean over LIVE dispatches (dispatches",
           "# skipped by the converged-CG early exit are excluded: counter > 50% of the kernel's max).",
           "# hbm_MB = (2*FETCH_SIZE + WRITE_SIZE) KB / 1e3   (gfx950: FETCH_SIZE under-reports 16 B/lane streaming reads by 2x)",
