@@ -207,7 +207,8 @@ int mgadmm_gather_windows(const void* series, int64_t n_steps, int32_t n_cols, i
 
 /* Per-kernel HIP-event timing on the launch stream (used by bench.py for the roofline figure).
  * tag 0 = sparse-Laplacian SpMM inside CG (the dominant kernel), 1 = CG vector update,
- * 2 = other SpMM launches, 3 = everything else. */
+ * 2 = other SpMM launches, 3 = everything else.  Speculative CG launches that found their solve converged and
+ * returned at the guard (a few microseconds, no operand traffic) are excluded from counts, time and bytes. */
 #define MGADMM_NPROF 4
 int mgadmm_prof_begin(mgadmm_solver* s);
 int mgadmm_prof_end(mgadmm_solver* s, int64_t* counts /*[MGADMM_NPROF]*/, double* total_ms /*[MGADMM_NPROF]*/,

@@ -74,6 +74,8 @@ struct Engine : EngineBase {
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_tag;
+    std::vector<double> prof_lb;   // algorithmic bytes of each timed launch
+    int64_t prof_noop = 0;         // timed launches that returned at the converged-CG guard
     size_t prof_used = 0;
     int64_t prof_count[MGADMM_NPROF] = {0};
     double prof_bytes[MGADMM_NPROF] = {0};
@@ -304,6 +306,7 @@ struct Engine : EngineBase {
             prof_ev.resize(2 * PROF_POOL);
             for (auto& e : prof_ev) MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));   // timing only: no system-scope cache flush per record
             prof_tag.resize(PROF_POOL);
+            prof_lb.resize(PROF_POOL);
         }
         prof_used = 0;
         for (int i = 0; i < MGADMM_NPROF; ++i) { prof_count[i] = 0; prof_bytes[i] = 0; }
@@ -313,19 +316,28 @@ struct Engine : EngineBase {
     int prof_end(int64_t* counts, double* total_ms, double* bytes) override {
         prof_on = false;
         MG_HIP(hipDeviceSynchronize());
-        double ms[MGADMM_NPROF] = {0};
+        double ms[MGADMM_NPROF] = {0}, by[MGADMM_NPROF] = {0};
         int64_t timed[MGADMM_NPROF] = {0};
+        prof_noop = 0;
         for (size_t i = 0; i < prof_used; ++i) {
             float f = 0;
             MG_HIP(hipEventElapsedTime(&f, prof_ev[2 * i], prof_ev[2 * i + 1]));
+            // A speculative CG launch that found its solve converged returns at the `live` guard after a few
+            // microseconds without touching its operands.  Such a launch cannot have moved its algorithmic
+            // bytes (the rate would be > 3x the HBM peak): it is left out of BOTH the bytes and the time, so the
+            // reported rates are those of launches that did the work.
+            if (prof_lb[i] > 0.0 && (double)f * 1e-3 < prof_lb[i] / 24.0e12) {
+                prof_noop++;
+                continue;
+            }
             ms[prof_tag[i]] += f;
+            by[prof_tag[i]] += prof_lb[i];
             timed[prof_tag[i]]++;
         }
         for (int i = 0; i < MGADMM_NPROF; ++i) {
-            // launches past the event pool are counted but not timed: scale bytes to the timed share
             counts[i] = timed[i];
             total_ms[i] = ms[i];
-            bytes[i] = prof_count[i] ? prof_bytes[i] * ((double)timed[i] / (double)prof_count[i]) : 0.0;
+            bytes[i] = by[i];
         }
         return MGADMM_OK;
     }
@@ -335,6 +347,7 @@ struct Engine : EngineBase {
         prof_bytes[tag] += bytes;
         if (tag == 3 || prof_used >= (size_t)PROF_POOL) return false;
         prof_tag[prof_used] = tag;
+        prof_lb[prof_used] = bytes;
         (void)hipEventRecord(prof_ev[2 * prof_used], st);
         return true;
     }

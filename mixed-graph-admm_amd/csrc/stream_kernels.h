@@ -13,6 +13,8 @@
 // range of time slice t and then the same eighth of slice t+1, which keeps the rows a time-shifted
 // operator (Ldr / Ldr^T) re-reads in that XCD's L2 / the Infinity Cache.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 template <typename S, int V>
@@ -144,6 +146,11 @@ __device__ __forceinline__ void row_entries(const int* __restrict__ colidx, cons
 // live: optional device flag; a zero value makes the launch a no-op (speculatively enqueued CG
 // iterations after every sample has converged).
 // ---------------------------------------------------------------------------------------------
+template <class E, class = void>
+struct has_fetch : std::false_type {};
+template <class E>
+struct has_fetch<E, std::void_t<typename E::Ops>> : std::true_type {};
+
 template <typename S, int VEC, class Epi, int GW>
 __global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __restrict__ rowptr,
                                               const int* __restrict__ colidx, const float* __restrict__ val,
@@ -229,6 +236,31 @@ __global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __re
                 ne1 = fe1;
             }
         } else {
+          if constexpr (has_fetch<Epi>::value) {
+           if (op.kind == OPK_NONE) {
+            // element-wise epilogue with a fetch/row_ops split: the loads of up to ROWS_IN_FLIGHT rows (input row
+            // + operand rows) are all issued before the first store, so a wave keeps 4x the bytes in flight
+            // (the stores of row k may alias the loads of row k+1 as far as the compiler knows, so it would
+            // not overlap them by itself).  Row order and arithmetic are unchanged.
+            constexpr int ROWS_IN_FLIGHT = 4;
+            for (; i < n1; i += 4 * ROWS_IN_FLIGHT) {
+                Vec<S, VEC> self[ROWS_IN_FLIGHT];
+                typename Epi::Ops ops[ROWS_IN_FLIGHT];
+                size_t off[ROWS_IN_FLIGHT];
+#pragma unroll
+                for (int k = 0; k < ROWS_IN_FLIGHT; ++k) {
+                    const int ik = min(i + 4 * k, n1 - 1);          // clamped: a short item re-reads its last row
+                    off[k] = ((size_t)t * g.N + ik) * g.Bp + col0;
+                    self[k] = ldv<S, VEC>(in + off[k]);
+                    ops[k] = epi.fetch(off[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < ROWS_IN_FLIGHT; ++k)
+                    if (i + 4 * k < n1) epi.row_ops(t, off[k], self[k], self[k], acc, ops[k]);
+            }
+            continue;
+           }
+          }
             for (; i < n1; i += 4) {
                 const size_t off = ((size_t)t * g.N + i) * g.Bp + col0;
                 const Vec<S, VEC> self = ldv<S, VEC>(in + off);
@@ -605,12 +637,15 @@ struct EpiCgUpdate {
     const S* alpha;
     S* r;
     S a[VEC];
+    struct Ops { Vec<S, VEC> r; };          // operand rows, fetched for several rows before any of them is stored
     __device__ void begin(int col0) {
 #pragma unroll
         for (int v = 0; v < VEC; ++v) a[v] = alpha[col0 + v];
     }
-    __device__ void row(int, size_t off, const Vec<S, VEC>& av, const Vec<S, VEC>&, S (*acc)[VEC]) {
-        Vec<S, VEC> rv = ldv<S, VEC>(r + off);
+    __device__ Ops fetch(size_t off) const { return Ops{ldv<S, VEC>(r + off)}; }
+    __device__ void row(int t, size_t off, const Vec<S, VEC>& av, const Vec<S, VEC>& l, S (*acc)[VEC]) { row_ops(t, off, av, l, acc, fetch(off)); }
+    __device__ void row_ops(int, size_t off, const Vec<S, VEC>& av, const Vec<S, VEC>&, S (*acc)[VEC], const Ops& o) {
+        Vec<S, VEC> rv = o.r;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             rv.v[v] = rv.v[v] - a[v] * av.v[v];
@@ -636,8 +671,11 @@ struct EpiPUpdate {
             b[v] = beta[col0 + v];
         }
     }
-    __device__ void row(int, size_t off, const Vec<S, VEC>& rv, const Vec<S, VEC>&, S (*)[VEC]) {
-        Vec<S, VEC> pv = ldv<S, VEC>(p + off), xv = ldv<S, VEC>(x + off);
+    struct Ops { Vec<S, VEC> p, x; };
+    __device__ Ops fetch(size_t off) const { return Ops{ldv<S, VEC>(p + off), ldv<S, VEC>(x + off)}; }
+    __device__ void row(int t, size_t off, const Vec<S, VEC>& rv, const Vec<S, VEC>& l, S (*acc)[VEC]) { row_ops(t, off, rv, l, acc, fetch(off)); }
+    __device__ void row_ops(int, size_t off, const Vec<S, VEC>& rv, const Vec<S, VEC>&, S (*)[VEC], const Ops& o) {
+        Vec<S, VEC> pv = o.p, xv = o.x;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             xv.v[v] = xv.v[v] + a[v] * pv.v[v];
@@ -658,11 +696,13 @@ struct EpiLin2 {
     S* out;
     S a, b;
     __device__ void begin(int) {}
-    __device__ void row(int, size_t off, const Vec<S, VEC>& u, const Vec<S, VEC>&, S (*)[VEC]) {
-        const Vec<S, VEC> wv = ldv<S, VEC>(w + off);
+    struct Ops { Vec<S, VEC> w; };
+    __device__ Ops fetch(size_t off) const { return Ops{ldv<S, VEC>(w + off)}; }
+    __device__ void row(int t, size_t off, const Vec<S, VEC>& u, const Vec<S, VEC>& l, S (*acc)[VEC]) { row_ops(t, off, u, l, acc, fetch(off)); }
+    __device__ void row_ops(int, size_t off, const Vec<S, VEC>& u, const Vec<S, VEC>&, S (*)[VEC], const Ops& ops) {
         Vec<S, VEC> o;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) o.v[v] = a * u.v[v] + b * wv.v[v];
+        for (int v = 0; v < VEC; ++v) o.v[v] = a * u.v[v] + b * ops.w.v[v];
         stv<S, VEC>(out + off, o);
     }
 };
