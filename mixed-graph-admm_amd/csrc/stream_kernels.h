@@ -33,8 +33,8 @@ __device__ __forceinline__ void stl(S* p, const Vec<S, V>& x) {
 }
 // Every vector the streaming kernels write is consumed by a LATER kernel, long after it has left the 4 MiB
 // L2 of its XCD: non-temporal stores keep the output from evicting the input slices the time-shifted
-// operators and the tile halos re-read (measured on cfg3: SpMM in CG 4.78 -> 4.84 TB/s, vector updates
-// 5.97 -> 6.02 TB/s).  Non-temporal LOADS were measured too and rejected: the tile kernel drops to 4.44 TB/s.
+// operators and the tile halos re-read (measured on cfg3: SpMM in CG and the vector updates each +1 %).
+// Non-temporal LOADS were measured too and rejected: the tile kernel loses 8 %.
 template <typename S, int V>
 __device__ __forceinline__ void stv(S* p, const Vec<S, V>& x) {
     if constexpr (V == 1) {
