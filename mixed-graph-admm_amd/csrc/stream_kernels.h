@@ -336,8 +336,8 @@ struct TileMeta {
 
 // MR = rows per wave (tile = 4*MR rows), a compile-time constant: the row loops are straight-line code (the
 // LDS reads of one row overlap the FMAs of the previous one, no per-row branches) and the register arrays
-// hold exactly MR rows.  Rows past the end of a short last tile are clamped to the tile's last row: they
-// recompute and re-store that row (same inputs, same values) and are kept out of the dot products.
+// hold exactly MR rows.  Rows past the end of a short last tile are clamped to the tile's last row for their
+// loads and gathers and skip the epilogue.
 template <typename S, int VEC, class Epi, int TILE_GW, int MR>
 __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* __restrict__ tl_col,
                                               const float* __restrict__ tl_w, const int* __restrict__ halo,
@@ -483,21 +483,9 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) l.v[v] = selfc * own[j].v[v] - sum.v[v];
                 const size_t off = ((size_t)t * g.N + rowi[j]) * g.Bp + col0;
-                if constexpr (Epi::NRED > 0) {
-                    S keep[NR][VEC];
-#pragma unroll
-                    for (int rr = 0; rr < NR; ++rr)
-#pragma unroll
-                        for (int v = 0; v < VEC; ++v) keep[rr][v] = acc[rr][v];
-                    if constexpr (Epi::HAS_PRE) epi.row_pre(t, off, own[j], l, acc, pre[j]);
-                    else epi.row(t, off, own[j], l, acc);
-                    if (!rowok[j]) {                        // clamped duplicate of the tile's last row: not summed twice
-#pragma unroll
-                        for (int rr = 0; rr < NR; ++rr)
-#pragma unroll
-                            for (int v = 0; v < VEC; ++v) acc[rr][v] = keep[rr][v];
-                    }
-                } else {
+                // rows past the end of a short last tile were clamped to its last row for the loads; their
+                // epilogue must not run (in-place epilogues such as the gamma / phi updates are not idempotent)
+                if (rowok[j]) {
                     if constexpr (Epi::HAS_PRE) epi.row_pre(t, off, own[j], l, acc, pre[j]);
                     else epi.row(t, off, own[j], l, acc);
                 }
