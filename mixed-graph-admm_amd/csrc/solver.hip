@@ -129,10 +129,12 @@ struct Engine : EngineBase {
     bool make_tile_geom(const Geom& q, TileGeom& tg) const {
         if (!use_tile || g->reorder < 2 || g->mode != MGADMM_TEMPORAL_SPATIAL) return false;
         tg.T = T; tg.N = N; tg.B = q.B; tg.Bp = q.Bp; tg.VEC = q.VEC; tg.CH = q.CH;
-        // tile size: 20 rows (5 per wave) measured best on the 10k-node graph (12..24 are within 2 %); 8-row
-        // tiles (2 per wave) when the problem would otherwise not fill the machine (>= 512 workgroups wanted).
-        // The rows per wave are a template parameter of k_tile, so only these two sizes exist.
-        int best = ((long)q.CH * ((N + 19) / 20) < 512) ? 8 : 20;
+        // tile size: 8 rows (2 per wave).  With the rows per wave a template constant the register footprint
+        // follows the tile size (EpiLhs: 100 VGPRs at 2 rows, 148 at 5), and the kernel is latency-bound, so
+        // more resident workgroups win: SpMM inside CG on the 10k-node graph 4.30 TB/s at 20 rows, 4.60 at 12,
+        // 4.72 at 8, 4.71 at 4 (more halo reads); the 100k-node graph is flat (4.86 -> 4.91).  MGADMM_TILE_R=20
+        // selects the large tile for experiments.
+        int best = 8;
         if (const char* e = getenv("MGADMM_TILE_R")) { int rr = atoi(e); if (rr == 8 || rr == 20) best = rr; }
         tg.R = best;
         tg.NTILE = (N + best - 1) / best;

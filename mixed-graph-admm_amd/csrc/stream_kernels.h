@@ -236,36 +236,39 @@ __global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __re
                 ne1 = fe1;
             }
         } else {
-          if constexpr (has_fetch<Epi>::value) {
-           if (op.kind == OPK_NONE) {
-            // element-wise epilogue with a fetch/row_ops split: the loads of up to ROWS_IN_FLIGHT rows (input row
-            // + operand rows) are all issued before the first store, so a wave keeps 4x the bytes in flight
-            // (the stores of row k may alias the loads of row k+1 as far as the compiler knows, so it would
-            // not overlap them by itself).  Row order and arithmetic are unchanged.
-            constexpr int ROWS_IN_FLIGHT = 4;
-            for (; i < n1; i += 4 * ROWS_IN_FLIGHT) {
-                Vec<S, VEC> self[ROWS_IN_FLIGHT];
-                typename Epi::Ops ops[ROWS_IN_FLIGHT];
-                size_t off[ROWS_IN_FLIGHT];
+            // element-wise epilogue with a fetch/row_ops split and no operator: the loads of up to ROWS_IN_FLIGHT
+            // rows (input row + operand rows) are all issued before the first store (the stores of row k may
+            // alias the loads of row k+1 as far as the compiler knows, so it would not overlap them by itself).
+            // Row order and arithmetic are unchanged; worth < 1 % (the kernels are bandwidth-bound).
+            bool done = false;
+            if constexpr (has_fetch<Epi>::value) {
+                if (op.kind == OPK_NONE) {
+                    constexpr int ROWS_IN_FLIGHT = 4;
+                    for (; i < n1; i += 4 * ROWS_IN_FLIGHT) {
+                        Vec<S, VEC> self[ROWS_IN_FLIGHT];
+                        typename Epi::Ops ops[ROWS_IN_FLIGHT];
+                        size_t off[ROWS_IN_FLIGHT];
 #pragma unroll
-                for (int k = 0; k < ROWS_IN_FLIGHT; ++k) {
-                    const int ik = min(i + 4 * k, n1 - 1);          // clamped: a short item re-reads its last row
-                    off[k] = ((size_t)t * g.N + ik) * g.Bp + col0;
-                    self[k] = ldv<S, VEC>(in + off[k]);
-                    ops[k] = epi.fetch(off[k]);
+                        for (int k = 0; k < ROWS_IN_FLIGHT; ++k) {
+                            const int ik = min(i + 4 * k, n1 - 1);      // clamped: a short item re-reads its last row
+                            off[k] = ((size_t)t * g.N + ik) * g.Bp + col0;
+                            self[k] = ldv<S, VEC>(in + off[k]);
+                            ops[k] = epi.fetch(off[k]);
+                        }
+#pragma unroll
+                        for (int k = 0; k < ROWS_IN_FLIGHT; ++k)
+                            if (i + 4 * k < n1) epi.row_ops(t, off[k], self[k], self[k], acc, ops[k]);
+                    }
+                    done = true;
                 }
-#pragma unroll
-                for (int k = 0; k < ROWS_IN_FLIGHT; ++k)
-                    if (i + 4 * k < n1) epi.row_ops(t, off[k], self[k], self[k], acc, ops[k]);
             }
-            continue;
-           }
-          }
-            for (; i < n1; i += 4) {
-                const size_t off = ((size_t)t * g.N + i) * g.Bp + col0;
-                const Vec<S, VEC> self = ldv<S, VEC>(in + off);
-                const Vec<S, VEC> l = op_apply_band<S, VEC>(g, op, band_w, in, t, i, col0, self);
-                epi.row(t, off, self, l, acc);
+            if (!done) {
+                for (; i < n1; i += 4) {
+                    const size_t off = ((size_t)t * g.N + i) * g.Bp + col0;
+                    const Vec<S, VEC> self = ldv<S, VEC>(in + off);
+                    const Vec<S, VEC> l = op_apply_band<S, VEC>(g, op, band_w, in, t, i, col0, self);
+                    epi.row(t, off, self, l, acc);
+                }
             }
         }
     }
