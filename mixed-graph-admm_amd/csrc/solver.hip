@@ -193,6 +193,17 @@ struct Engine : EngineBase {
                 }
                 for (size_t k = 0; k < hl.size(); ++k) halo[(size_t)tl * TILE_HMAX + k] = hl[k];
             }
+            if (getenv("MGADMM_TILE_STATS")) {           // diagnostics: how well the tile geometry fits the graph
+                long hsum = 0; int hfull = 0;
+                for (int tl = 0; tl < ntile; ++tl) {
+                    int c = 0;
+                    for (int k = 0; k < TILE_HMAX; ++k) c += halo[(size_t)tl * TILE_HMAX + k] >= 0;
+                    hsum += c; hfull += c == TILE_HMAX;
+                }
+                fprintf(stderr, "[mgadmm] tile_meta matrix %d: R=%d GW=%d tiles=%d  halo rows/tile mean %.2f (capacity %d, full tiles %d)  "
+                                "entries %d, overflow entries %zu (%.2f %%)\n", which, R, TILE_GW, ntile, (double)hsum / ntile, TILE_HMAX,
+                        hfull, A.nnz(), hcol.size(), 100.0 * hcol.size() / std::max(1, A.nnz()));
+            }
             MG_HIP(hipStreamSynchronize(st));
             auto fr = [](void* q) { if (q) (void)hipFree(q); };
             fr(d.tl_col); fr(d.tl_w); fr(d.halo); fr(d.h_rowptr); fr(d.h_col); fr(d.h_val);

@@ -318,7 +318,7 @@ struct TileGeom {
 };
 constexpr int TILE_MAXR = 8;    // rows per wave and time step (4 waves -> R <= 32)
 constexpr int TILE_GW_MAX = 8;  // neighbour slots per row held in VGPR lanes: 4 (W_u), 6 (W_d) or 8 (W_d^T); MAXR*GW <= 64
-constexpr int TILE_HMAX = 16;   // halo rows (out-of-tile neighbours) staged in LDS per tile and step
+constexpr int TILE_HMAX = 20;   // halo rows (out-of-tile neighbours) staged in LDS per tile and step
 constexpr int TILE_HPW = TILE_HMAX / 4;   // halo rows loaded by one wave
 
 // Per-(matrix, R) metadata built on the host (Engine::tile_meta):
@@ -459,17 +459,24 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) sum.v[v] = S(0);
                 if (tvalid) {
-                    Vec<S, VEC> nv[TILE_GW];
+                    // neighbour rows in batches of at most 4 LDS reads (keeps the register footprint at 4 rows:
+                    // one more resident workgroup per CU than with all TILE_GW reads in flight)
+                    constexpr int GB = TILE_GW > 4 ? TILE_GW / 2 : TILE_GW;
 #pragma unroll
-                    for (int u = 0; u < TILE_GW; ++u) {
-                        const int lc = __builtin_amdgcn_readlane(mcol, j * TILE_GW + u);
-                        nv[u] = ldv<S, VEC>(trow + (size_t)lc * W);
-                    }
+                    for (int u0 = 0; u0 < TILE_GW; u0 += GB) {
+                        Vec<S, VEC> nv[GB];
 #pragma unroll
-                    for (int u = 0; u < TILE_GW; ++u) {
-                        const S w = (S)__int_as_float(__builtin_amdgcn_readlane(mw, j * TILE_GW + u));
+                        for (int u = 0; u < GB; ++u) {
+                            const int lc = __builtin_amdgcn_readlane(mcol, j * TILE_GW + u0 + u);
+                            nv[u] = ldv<S, VEC>(trow + (size_t)lc * W);
+                        }
 #pragma unroll
-                        for (int v = 0; v < VEC; ++v) sum.v[v] += w * nv[u].v[v];
+                        for (int u = 0; u < GB; ++u) {
+                            const S w = (S)__int_as_float(__builtin_amdgcn_readlane(mw, j * TILE_GW + u0 + u));
+#pragma unroll
+                            for (int v = 0; v < VEC; ++v) sum.v[v] += w * nv[u].v[v];
+                        }
+                        if (TILE_GW > GB) __builtin_amdgcn_sched_barrier(0);   // do not merge the batches again
                     }
                     const int hcount = __builtin_amdgcn_readlane(hc, j);   // overflow entries (normally 0)
                     if (hcount > 0) {
