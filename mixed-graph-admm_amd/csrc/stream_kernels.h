@@ -876,17 +876,19 @@ __global__ __launch_bounds__(1024) void k_reduce(const S* __restrict__ partials,
     double s[NRED];
 #pragma unroll
     for (int r = 0; r < NRED; ++r) s[r] = 0.0;
-    // 8 partial rows per trip: the loads are issued together (the kernel is pure latency: 8 workgroups, up to
-    // ~80 rows per wave), the additions stay in row order -- same sums, bit for bit
+    // RB partial rows per trip: the loads are issued together (the kernel is pure latency: Bp/64 workgroups, up
+    // to ~80 rows per wave on the 10k-node graph, ~800 on the 100k-node one), the additions stay in row order
+    // -- same sums, bit for bit
+    constexpr int RB = NRED <= 2 ? 16 : 8;
     int p = wave;
-    for (; p + 7 * 16 < P; p += 8 * 16) {
-        S v[8][NRED];
+    for (; p + (RB - 1) * 16 < P; p += RB * 16) {
+        S v[RB][NRED];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < RB; ++k)
 #pragma unroll
             for (int r = 0; r < NRED; ++r) v[k][r] = partials[((size_t)r * P + p + 16 * k) * Bp + c];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int k = 0; k < RB; ++k)
 #pragma unroll
             for (int r = 0; r < NRED; ++r) s[r] += (double)v[k][r];
     }
