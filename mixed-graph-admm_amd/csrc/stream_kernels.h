@@ -301,10 +301,11 @@ __global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __re
 // The tile's rows of the slice the gathers read (t + shift: the slice the workgroup streamed in its
 // previous step, or the current one for Lu) are kept in LDS, so an in-tile neighbour costs one
 // conflict-free ds_read_b128 instead of a trip through L1/L2, and every slice is fetched from HBM once
-// instead of twice (once as "own" rows, once as gathered rows).  Out-of-tile neighbours (the halo, ~10-15 %
-// of the entries under the cluster order) are read from global memory; consecutive tiles run on the same
-// XCD, so the halo usually hits that XCD's L2.  Own rows of a step are loaded up front (MAXR x 1 KiB per
-// wave in flight), the epilogue functors are the ones of k_rows.
+// instead of twice (once as "own" rows, once as gathered rows).  The rows of out-of-tile neighbours (the
+// halo: 7.6 rows per 8-row tile on the 10k-node kNN graph, up to TILE_HMAX) are staged in LDS once per step;
+// consecutive tiles run on the same XCD, so those loads often hit that XCD's L2.  The own rows of step s+1
+// are requested while step s computes; the epilogue functors are the ones of k_rows.  The kernel is
+// latency-bound (VALU ~25 %, LDS ~15-30 % busy, waits > 50 %): small tiles / many resident workgroups win.
 // ---------------------------------------------------------------------------------------------
 struct TileGeom {
     int T, N, B, Bp;
