@@ -83,6 +83,23 @@ struct BlockRed {
         par ^= 1;
         return s;
     }
+    // Same exchange for the CG dot products, float in / float out: after the barrier every lane reads ONE of the
+    // 16 wave totals (slot lane & 15) and the 16 values are summed inside each 16-lane row with DPP row shifts
+    // (all four rows compute the same sum in the same order); lane 15's value is broadcast.  8 VALU + 1 ds_read
+    // instead of 15 VALU + 4 ds_read_b128 + two float<->double conversions per reduction.
+    __device__ __forceinline__ float sumf(float v) {
+        v = wave_sum(v);
+        float* buf = red + par * 16;
+        if (lane == 0) buf[wave] = v;
+        __syncthreads();
+        float t = buf[lane & 15];
+        t = dpp_step<0x111, 0xf>(t);   // row_shr:1
+        t = dpp_step<0x112, 0xf>(t);   // row_shr:2
+        t = dpp_step<0x114, 0xf>(t);   // row_shr:4
+        t = dpp_step<0x118, 0xf>(t);   // row_shr:8   -> lane 15 of every row: sum of the 16 slots
+        par ^= 1;
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 15));
+    }
 };
 
 // vector access to TPG consecutive floats in LDS (alignment: TPG*4 B when TPG is a multiple of 4, 8 B when
@@ -340,13 +357,13 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, 
         pv[k] = r[k];                    // p = r
         part += r[k] * r[k];
     }
-    float rr = (float)br.sum(part);      // barrier: every read of P (= x0) is done
+    float rr = br.sumf(part);            // barrier: every read of P (= x0) is done
     c.put(c.P, pv);
     int iters = -1;
     for (int it = 0; it < max_cg; ++it) {
         __syncthreads();                 // p complete in LDS
         part = lds_apply<TPG, BAND, KIND>(c, pv, av, dc, c2);
-        const float pAp = (float)br.sum(part);   // barrier: every gather from P/Q of this iteration is done
+        const float pAp = br.sumf(part);         // barrier: every gather from P/Q of this iteration is done
         const float alpha = rr / pAp;
         part = 0.f;
 #pragma unroll
@@ -355,7 +372,7 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, 
             r[k] = r[k] - alpha * av[k];
             part += r[k] * r[k];
         }
-        const float rrn = (float)br.sum(part);
+        const float rrn = br.sumf(part);
         const float beta = rrn / rr;
         rr = rrn;
         if (ah != nullptr && threadIdx.x == 0) {
