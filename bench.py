@@ -192,8 +192,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the first HIP call (dmabuf IPC for RCCL)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # one process per GPU; MGADMM_DIST_BACKEND=gloo (+ several ranks sharing a GPU) exists only to rehearse the
     # multi-rank control flow on a one-GPU box
     backend = os.environ.get("MGADMM_DIST_BACKEND", "nccl")
