@@ -17,13 +17,28 @@ def shard_bounds(B, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def sharded_solve(solve_fn, y, mask=None, *, gather=True, group=None):
+def _gather_blocks(xs, n_local, width, tail, dtype, dev, ws, group, async_op):
+    """all_gather of one equal-size padded block per rank; returns (parts, work)."""
+    buf = torch.zeros((width,) + tail, dtype=dtype, device=dev)
+    if xs is not None and n_local > 0:
+        buf[:n_local] = xs.to(dev)
+    parts = [torch.empty_like(buf) for _ in range(ws)]
+    work = dist.all_gather(parts, buf, group=group, async_op=async_op)
+    return parts, work
+
+
+def sharded_solve(solve_fn, y, mask=None, *, gather=True, group=None, chunks=1):
     """Run ``solve_fn(y_shard, mask_shard) -> x_shard`` on this rank's batch block and gather the shards.
 
     ``solve_fn`` is normally ``ADMM_algorithm.combined_loop`` bound to a solver on this rank's GPU.
     With ``gather=True`` every rank returns the full (B,T,N,C) tensor (all_gather of equal-size padded
     blocks); with ``gather=False`` each rank returns only its block.  Works without an initialised
     process group (world_size 1).
+
+    ``chunks > 1`` cuts the rank's block into that many sub-blocks that are solved one after the other; the
+    all_gather of sub-block c is issued asynchronously (RCCL runs it on its own stream) and overlaps the solve
+    of sub-block c+1, so only the last sub-block's exchange is exposed.  Samples are independent, so the result
+    does not depend on ``chunks``.
     """
     if dist.is_available() and dist.is_initialized():
         ws, rk = dist.get_world_size(group), dist.get_rank(group)
@@ -31,32 +46,48 @@ def sharded_solve(solve_fn, y, mask=None, *, gather=True, group=None):
         ws, rk = 1, 0
     B = y.shape[0]
     lo, hi = shard_bounds(B, ws, rk)
-    ys = y[lo:hi]
-    ms = mask[lo:hi] if mask is not None else None
-    xs = solve_fn(ys, ms) if hi > lo else None
+    chunks = max(1, int(chunks))
     if not gather or ws == 1:
-        return xs
-    # equal-size blocks for all_gather: pad to the largest shard
-    width = (B + ws - 1) // ws
-    shape = None
-    if xs is not None:
-        shape = torch.tensor(list(xs.shape[1:]), dtype=torch.int64)
-    # every rank has at least one sample unless B < world_size; handle the empty case by broadcasting the shape
-    shp = [torch.zeros(3, dtype=torch.int64) for _ in range(ws)]
+        if hi <= lo:
+            return None
+        outs = []
+        for c in range(chunks):
+            a, b = shard_bounds(hi - lo, chunks, c)
+            if b > a:
+                outs.append(solve_fn(y[lo + a:lo + b], mask[lo + a:lo + b] if mask is not None else None))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    mine = (shape if shape is not None else torch.zeros(3, dtype=torch.int64)).to(dev)
-    shp = [s.to(dev) for s in shp]
-    dist.all_gather(shp, mine, group=group)
-    tail = next(tuple(int(v) for v in s.tolist()) for s in shp if int(s.sum()) > 0)
-    dtype = xs.dtype if xs is not None else y.dtype
-    buf = torch.zeros((width,) + tail, dtype=dtype, device=dev)
-    if xs is not None:
-        buf[: hi - lo] = xs.to(dev)
-    parts = [torch.empty_like(buf) for _ in range(ws)]
-    dist.all_gather(parts, buf, group=group)
+    width = (B + ws - 1) // ws                       # largest shard
+    cwidth = (width + chunks - 1) // chunks          # largest sub-block of any rank
+    pending = []                                     # (parts, work) per sub-block
+    tail, dtype = None, None
+    for c in range(chunks):
+        a, b = shard_bounds(hi - lo, chunks, c)
+        xs = None
+        if b > a:
+            xs = solve_fn(y[lo + a:lo + b], mask[lo + a:lo + b] if mask is not None else None)
+        if tail is None:
+            # trailing shape / dtype: every rank has at least one sample unless B < world_size
+            mine = torch.zeros(4, dtype=torch.int64)
+            if xs is not None:
+                mine[:3] = torch.tensor(list(xs.shape[1:]), dtype=torch.int64)
+                mine[3] = 1 if xs.dtype == torch.float64 else 0
+            shp = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(ws)]
+            dist.all_gather(shp, mine.to(dev), group=group)
+            first = next(s for s in shp if int(s[:3].sum()) > 0)
+            tail = tuple(int(v) for v in first[:3].tolist())
+            dtype = xs.dtype if xs is not None else (torch.float64 if int(first[3]) else torch.float32)
+        pending.append(_gather_blocks(xs, b - a, cwidth, tail, dtype, dev, ws, group, async_op=chunks > 1 and c < chunks - 1))
     out = []
     for r in range(ws):
         l2, h2 = shard_bounds(B, ws, r)
-        out.append(parts[r][: h2 - l2])
+        for c in range(chunks):
+            a, b = shard_bounds(h2 - l2, chunks, c)
+            parts, work = pending[c]
+            if work is not None:
+                work.wait()
+                pending[c] = (parts, None)
+            if b > a:
+                out.append(parts[r][: b - a])
     return torch.cat(out, 0).to(y.device if backend != "nccl" else dev)

@@ -38,6 +38,12 @@ def _worker(rank, world, port, B, out_dir):
     lo, hi = shard_bounds(B, world, rank)
     assert calls == ([hi - lo] if hi > lo else [])
     xs = sharded_solve(solve_fn, y, gather=False)
+    # sub-blocks with asynchronous gathers: same result, one solve call per non-empty sub-block
+    calls.clear()
+    xc = sharded_solve(solve_fn, y, chunks=3)
+    assert torch.equal(xc, x)
+    assert sum(calls) == hi - lo and len(calls) == min(3, hi - lo)
+    assert torch.equal(sharded_solve(solve_fn, y, gather=False, chunks=2), xs) if xs is not None else True
     np.save(os.path.join(out_dir, f"x_rank{rank}.npy"), x.numpy())
     if xs is not None:
         np.save(os.path.join(out_dir, f"shard_rank{rank}.npy"), xs.numpy())
