@@ -119,6 +119,37 @@ def test_channels_fold_into_nodes():
     blk.close()
 
 
+@pytest.mark.parametrize("mode,task", [("knn", "pred"), ("knn", "mask"), ("skip3", "pred")])
+def test_multi_channel_full_solve(mode, task):
+    """C = 3 channels: one CG system per sample over (T, N, C) (alpha, beta and the convergence test are shared
+    by the channels, ADMM.py:347-360).  The product folds channels into the node axis; float64 kernels vs the
+    oracle, and the float32 paths (the folded graph has 90 nodes: LDS path at TPG = 3)."""
+    meta = load_golden("g4_meta.npz")
+    rng = np.random.default_rng(11)
+    B, C_ = 3, 3
+    x_true = 100 + 50 * rng.standard_normal((B, 24, 30, C_))
+    if task == "pred":
+        y, mask = x_true[:, :12].copy(), None
+    else:
+        mask = (rng.random(x_true.shape) >= 0.4).astype(np.float32)
+        y = x_true * mask
+    o = make_oracle(meta, mode)
+    xo = o.combined_loop(y, mask=mask, n_iters=5)
+    for kw, xtol, htol, slack in ((dict(compute_dtype=torch.float64), 1e-10, 1e-8, 0), (dict(path="lds"), 1e-5, 1e-3, 1),
+                                  (dict(path="stream"), 1e-5, 1e-3, 1)):
+        blk = make_product(meta, mode, **kw)
+        blk.max_ADMM_iter = 5
+        blk.check_stop = False
+        # float32 mask like utils.py:129 (the reference's time moments are float32 then)
+        x = blk.combined_loop(T_(y), mask=torch.from_numpy(mask) if mask is not None else None, print_info=False)
+        assert tuple(x.shape) == (B, 24, 30, C_) and rel(x, xo) < xtol, kw
+        floor = (1e-8 if htol >= 1e-4 else 1e-14) * float(np.linalg.norm(xo))
+        np.testing.assert_allclose(np.array(blk.p_res_list), np.array(o.hist.p_res_list), rtol=htol, atol=floor)
+        got = torch.stack(blk.CG_iter_x).numpy()
+        assert np.abs(got - np.array(o.hist.CG_iter_x)).max() <= slack
+        blk.close()
+
+
 # ------------------------------------------------------------------ KATs (G6)
 def test_line_graph_kats_and_phi_direct():
     from mgadmm.ADMM import ADMM_algorithm
