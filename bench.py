@@ -16,10 +16,20 @@ Workloads (BASELINE.json configs; synthetic data, seeds fixed, see SURVEY.md sec
   cfg4           N=100 000 mixed graph, B=256 per GPU (weak scaling 1..8 GPUs), fp32
 Metric: ADMM sample-iterations per second = (samples over all ranks) * K / seconds.
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events recorded around every launch
-of the dominant kernel (the sparse-Laplacian SpMM inside the CG solves) on the launch stream, during the
-timed solve; `cpu_baseline` is the CPU oracle (a NumPy/SciPy port of the reference algorithm, 1 thread)
-timed on a bounded sample of the same workload on the host cores.
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of the timed workload, measured live with
+HIP events recorded around every launch on the launch stream during the timed solve:
+  * cfg2 (LDS-resident path): k_admm_lds never streams its vectors from HBM, so it is priced against the LDS:
+    `bound` = "lds", `achieved` = LDS bytes the kernel's gathers / stores move per launch (exact count from the CSR
+    row lengths, the time-group width and the CG iteration counts of the timed solve) / average launch duration,
+    `peak` = 150 TB/s (MI355X_MICROARCH.md: aggregate ds_read_b128 rate); `traffic` = HBM bytes per launch from the
+    rocprofv3 PMC passes, `hbm_achieved` = traffic / duration.
+  * cfg3 / cfg4 (streaming path): the sparse-Laplacian SpMM inside the CG solves against the HBM roofline
+    (`bound` = "hbm", 8 TB/s), algorithmic bytes per launch as accumulated by the library.
+The default (cfg2) run also measures the cfg3 SpMM roofline -- the configuration the >= 60 % target is quoted on -- over
+5 ADMM iterations (> 200 live launches); its figures are flattened into the same `roofline` object as `cfg3_spmm_*`.
+`cpu_baseline` is the CPU oracle (NumPy/SciPy restatement of the reference) on a bounded sample of the same windows:
+one worker process per host core (at most 16, the GPU box's CPU share), each solving its windows one at a time
+(B = 1: the reference's semantics), plus the vectorised-batch rate of one core and the full cfg1 run.
 """
 import argparse
 import json
@@ -38,7 +48,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+LDS_PEAK_GBS = 150000.0  # aggregate ds_read_b64/b128 rate with every CU streaming (MI355X_MICROARCH.md, LDS section)
 
 
 def pems_like_graph(n, n_edges, seed=0):
@@ -113,24 +124,77 @@ def make_solver(n, cl, dl, info, device):
     return blk
 
 
-def cpu_baseline(n, cl, info, blk, y_dev, budget_s, steps):
-    """Oracle (CPU port of the reference algorithm) on a bounded sample of the same workload."""
+def _oracle_inputs(cl, blk, info, y_dev, path):
+    np.savez(path, cl=cl.numpy(), u_ew=blk.u_ew[0].numpy(), d_ew=blk.d_ew[0].numpy(), y=y_dev.double().cpu().numpy(),
+             t_in=12, T=24, **{k: float(v) for k, v in info.items()})
+
+
+def _run_workers(npz, bounds, mode, iters):
+    """Start one oracle worker per (lo, hi) slice, release them together, return (wall seconds, samples)."""
+    import subprocess
+    worker = os.path.join(ROOT, "oracle", "cpu_bench_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, npz, str(lo), str(hi), mode, str(iters)], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, text=True) for lo, hi in bounds]
+    for p in procs:
+        assert p.stdout.readline().strip() == "READY"
+    t0 = time.perf_counter()
+    for p in procs:
+        p.stdin.write("go\n"); p.stdin.flush()
+    outs = [json.loads(p.stdout.readline()) for p in procs]
+    dt = time.perf_counter() - t0
+    for p in procs:
+        p.wait()
+    return dt, sum(o["samples"] for o in outs)
+
+
+def cpu_baseline(workload, n, cl, info, blk, y_dev, budget_s, steps):
+    """Oracle (CPU restatement of the reference algorithm) on a bounded sample of the same workload, per
+    BASELINE.md section 4: every host core the box gives one GPU job (<= 16 worker processes, one core each), the
+    per-sample loop (B = 1, the reference's own semantics) AND the vectorised batch; cfg1 timed in full."""
+    import tempfile
     from oracle import admm_oracle as orc
+    ncpu = os.cpu_count() or 1
+    workers = max(1, min(16, ncpu))
+    tmp = tempfile.mkdtemp(prefix="mgadmm_cpu_")
+    # calibrate one core (vectorised, 8 windows x 2 iterations), then size the sample to ~budget_s/2 per mode
     o = orc.OracleADMM(cl.numpy(), blk.u_ew[0].numpy(), blk.d_ew[0].numpy(), info, mode="knn", t_in=12, T=24)
-    # calibrate on a small slice, then size the timed sample to ~budget_s seconds of CPU work
-    yc0 = y_dev[:8].double().cpu().numpy()
+    ncal = min(8, y_dev.shape[0])
+    yc0 = y_dev[:ncal].double().cpu().numpy()
     t0 = time.perf_counter()
     o.combined_loop(yc0, n_iters=2)
-    per = (time.perf_counter() - t0) / 16.0              # seconds per sample-iteration (vectorised over 8)
-    it = max(1, min(steps, 10))
-    Bc = int(max(1, min(y_dev.shape[0], budget_s / max(per * it, 1e-9))))
-    yc = y_dev[:Bc].double().cpu().numpy()
-    t0 = time.perf_counter()
-    o.combined_loop(yc, n_iters=it)
-    dt = time.perf_counter() - t0
-    return {"value": Bc * it / dt, "unit": "ADMM sample-iterations/s", "cores": 1, "kind": "port",
-            "sample": f"{Bc} samples x {it} ADMM iterations of the same workload, float64, NumPy/SciPy oracle "
-                      f"(vectorised over the batch, per-sample CG convergence), {dt:.1f} s on 1 of {os.cpu_count()} host cores"}
+    per = (time.perf_counter() - t0) / (2.0 * ncal)                 # seconds per sample-iteration, one core, vectorised
+    it = max(1, min(steps, 20))
+    nb = int(max(1, min(y_dev.shape[0], 64, (budget_s / 3) / max(per * it, 1e-9))))      # vectorised batch on one core
+    nl = int(max(workers, min(y_dev.shape[0], workers * (budget_s / 2) / max(per * it, 1e-9))))
+    npz = os.path.join(tmp, "in.npz")
+    _oracle_inputs(cl, blk, info, y_dev[:max(nb, nl)], npz)
+    from mgadmm.dist import shard_bounds
+    dt_loop, ns = _run_workers(npz, [shard_bounds(nl, workers, w) for w in range(workers) if shard_bounds(nl, workers, w)[1] > shard_bounds(nl, workers, w)[0]], "loop", it)
+    nw = min(workers, nl)
+    dt_vec, nv = _run_workers(npz, [(0, nb)], "batch", it)
+    out = {"value": ns * it / dt_loop, "unit": "ADMM sample-iterations/s", "cores": nw, "kind": "port",
+           "sample": f"{ns} windows of the same workload x {it} ADMM iterations, float64 NumPy/SciPy oracle, one window at a "
+                     f"time (B=1, reference semantics) on {nw} worker processes = {nw} of {ncpu} host cores, {dt_loop:.1f} s",
+           "host_cpu_count": ncpu,
+           "vectorised_1core_value": nv * it / dt_vec,
+           "vectorised_1core_sample": f"{nv} windows x {it} iterations as one batch on 1 core, {dt_vec:.1f} s"}
+    if workload != "cfg1":
+        try:
+            n1, _, cl1, dl1, info1, _ = build_problem("cfg1")
+            import mgadmm
+            b1 = mgadmm.ADMM_algorithm({"n_nodes": n1}, info1, use_kNN=True, k=4, u_sigma=50, d_sigma=50, tables=(cl1, dl1))
+            y1 = 300 * torch.rand(1, 12, n1, 1, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+            npz1 = os.path.join(tmp, "cfg1.npz")
+            _oracle_inputs(cl1, b1, info1, y1, npz1)
+            b1.close()
+            dt1, _ = _run_workers(npz1, [(0, 1)], "loop", 50)
+            out["cfg1_full_run"] = f"N=170, B=1, float64, 50 ADMM iterations on 1 core: {dt1:.2f} s = {50 / dt1:.1f} ADMM it/s"
+            out["cfg1_full_run_it_per_s"] = 50 / dt1
+        except Exception as e:  # noqa: BLE001
+            out["cfg1_full_run"] = f"failed: {e!r}"
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return out
 
 
 def load_traffic(workload):
@@ -143,36 +207,56 @@ def load_traffic(workload):
         return None
 
 
-def roofline_from_prof(prof, workload, path="stream", elems=0, cg=None):
-    """Roofline object of the dominant kernel from the live HIP-event timings (tag 0).
+def lds_bytes_per_launch(blk, B, cg, T=24):
+    """LDS bytes one k_admm_lds launch (= one ADMM iteration of B samples) moves, counted from what the kernel issues
+    (csrc/lds_kernels.h): per CSR entry and time group one entry read (8 B) + ceil(TPG/4) aligned 16-B row reads, + one
+    more 16-B group holding the edge element for the time-shifted operators; per operator application one 4-B store per
+    element.  Operator applications: x / zd solves (K+1) x (Ldr + Ldr^T), zu solve (K+1) x Lu, + RHS_x (Ldr^T),
+    phi prox (Ldr) and GLR (Lu).  K = measured mean CG iterations of the timed solve."""
+    from mgadmm import _lib
+    h = blk._solvers[(1, torch.float32)][0]
+    tpg = _lib.query(h, _lib.Q_LDS_TPG)
+    G = T // tpg
+    nu, nd, nt = (_lib.query(h, q) for q in (_lib.Q_NNZ_U, _lib.Q_NNZ_D, _lib.Q_NNZ_DT))
+    run = ((tpg + 3) // 4) * 16 if tpg % 4 == 0 else tpg * 4
+    edge = 16 if tpg % 4 == 0 else 4
+    per_lu = G * nu * (8 + run)
+    per_ldr = G * nd * (8 + run + edge)
+    per_ldrt = G * nt * (8 + run + edge)
+    TN = T * blk.n_nodes
+    store = TN * 4
+    kx, kzu, kzd = cg["CG_iter_x"], cg["CG_iter_zu"], cg["CG_iter_zd"]
+    per_sample = ((kx + 1) + (kzd + 1)) * (per_ldr + per_ldrt + 2 * store) + (kzu + 1) * (per_lu + store) \
+        + (per_ldrt + store) + (per_ldr + store) + per_lu
+    return B * per_sample, tpg
 
-    stream path: dominant kernel = the sparse-Laplacian SpMM inside the CG solves; algorithmic bytes are
-                 accumulated per launch by the library (8 B/element per SpMM pass + CSR bytes).
-    lds path   : dominant kernel = k_admm_lds (one launch = one whole ADMM iteration, CG loops inside LDS);
-                 algorithmic bytes per launch follow SURVEY.md 8(d): U * [52 (Kx+1) + 44 (Kzu+1) + 52 (Kzd+1)
-                 + 130] B with the measured mean CG counts.  These bytes never reach HBM on this path, so
-                 `achieved` can exceed the HBM peak; `traffic` is the HBM traffic measured with rocprofv3."""
+
+def roofline_from_prof(prof, workload, path="stream", blk=None, B=0, cg=None):
+    """Roofline object of the dominant kernel from the live HIP-event timings (tag 0); see the module docstring."""
     p0 = prof[0]
     if p0["count"] == 0 or p0["ms"] <= 0:
         return None
     avg_ms = p0["ms"] / p0["count"]
+    traffic = load_traffic(workload)
     if path == "lds":
-        per_elem = 52 * (cg["CG_iter_x"] + 1) + 44 * (cg["CG_iter_zu"] + 1) + 52 * (cg["CG_iter_zd"] + 1) + 130
-        bytes_per = per_elem * elems
-        kernel = "k_admm_lds<TPG> (LDS-resident fused ADMM iteration: 3 CG solves + prox + duals + history per launch)"
-    else:
-        bytes_per = p0["bytes"] / p0["count"]
-        kernel = "k_tile / k_rows <SpMM in CG> (sparse mixed-graph Laplacian, batch-innermost; LDS-tiled on cluster-ordered graphs)"
+        bytes_per, tpg = lds_bytes_per_launch(blk, B, cg)
+        ach = bytes_per / (avg_ms * 1e-3) / 1e9
+        out = {"bound": "lds", "kernel": f"k_admm_lds<TPG={tpg}> (LDS-resident fused ADMM iteration: 3 CG solves + prox + duals + "
+                                         "history per launch; one workgroup per sample)",
+               "achieved": ach, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": ach / LDS_PEAK_GBS, "traffic": traffic,
+               "launches": p0["count"], "avg_launch_us": avg_ms * 1e3, "lds_bytes_per_launch": bytes_per,
+               "hbm_achieved": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
+               "hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+               "note": "vectors live in LDS/registers inside the CG solves: priced against the LDS pipe; `traffic`/`hbm_*` = HBM bytes "
+                       "per launch from rocprofv3 PMC (state in/out only); the HBM-streaming SpMM roofline is in cfg3_spmm_*"}
+        return out
+    bytes_per = p0["bytes"] / p0["count"]
     ach = bytes_per / (avg_ms * 1e-3) / 1e9
-    out = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(workload), "launches": p0["count"],
-           "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": bytes_per}
-    if path == "lds":
-        out["note"] = ("algorithmic bytes (SURVEY 8d) are served from LDS/registers on this path; see `traffic` for the "
-                       "HBM bytes actually moved and `roofline_cfg3` for the HBM-streaming SpMM kernel")
-    else:
-        out["cg_update_kernel_GBs"] = (prof[1]["bytes"] / max(prof[1]["ms"], 1e-9) / 1e6) if prof[1]["count"] else None
-    return out
+    return {"bound": "hbm", "kernel": "sparse mixed-graph Laplacian SpMM inside CG (k_tile / k_rows, batch-innermost; LDS-tiled on "
+                                      "cluster-ordered graphs)",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "launches": p0["count"], "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": bytes_per,
+            "cg_update_kernel_GBs": (prof[1]["bytes"] / max(prof[1]["ms"], 1e-9) / 1e6) if prof[1]["count"] else None}
 
 
 def main():
@@ -266,10 +350,8 @@ def main():
                        "mean_cg_iters": cg_counts, "solver_path": path, "all_finite": finite,
                        "workspace_GB": blk.workspace_bytes() / 1e9, "per_kernel_events_in_timed_region": not args.no_prof},
         }
-        if prof:
-            out["roofline"] = roofline_from_prof(prof, args.workload, path, elems=B * 24 * n, cg=cg_counts)
-        else:
-            out["roofline"] = None
+        out["config"]["mean_cg_iters_x_zu_zd"] = [round(cg_counts[k2], 2) for k2 in ("CG_iter_x", "CG_iter_zu", "CG_iter_zd")]
+        out["roofline"] = roofline_from_prof(prof, args.workload, path, blk=blk, B=B, cg=cg_counts) if prof else None
 
     # ---- CG-SpMV roofline leg on the 10k-node graph (BASELINE config 3), rank 0 of a 1-GPU run only
     if rank == 0 and world == 1 and args.workload == "cfg2" and not args.no_cfg3_leg:
@@ -282,7 +364,8 @@ def main():
         b3.max_ADMM_iter = 1
         b3.combined_loop(y3, print_info=False)
         torch.cuda.synchronize()
-        b3.max_ADMM_iter = 2
+        it3 = 5                                   # > 200 live SpMM-in-CG launches
+        b3.max_ADMM_iter = it3
         b3._reset_history()
         b3.prof_begin()
         t0 = time.perf_counter()
@@ -291,8 +374,12 @@ def main():
         dt3 = time.perf_counter() - t0
         r3 = roofline_from_prof(b3.prof_end(), "cfg3")
         if r3:
-            r3["config"] = f"cfg3: {desc3}, B={B3}, fp32, 2 ADMM iterations"
-            r3["sample_iterations_per_s"] = B3 * 2 / dt3
+            r3["config"] = f"cfg3: {desc3}, B={B3}, fp32, {it3} ADMM iterations"
+            r3["sample_iterations_per_s"] = B3 * it3 / dt3
+            if out.get("roofline"):
+                for k3 in ("bound", "achieved", "peak", "frac", "traffic", "launches", "avg_launch_us",
+                           "algorithmic_bytes_per_launch", "cg_update_kernel_GBs", "sample_iterations_per_s"):
+                    out["roofline"]["cfg3_spmm_" + k3] = r3[k3]
         out["roofline_cfg3"] = r3
         b3.close()
 
@@ -300,8 +387,8 @@ def main():
         try:
             nb, Bb, clb, dlb, infob, _ = build_problem(args.workload)
             bb = make_solver(nb, clb, dlb, infob, device)
-            yb = synth_y(nb, min(512, B), 12, seed=1, offset=0, device=device)
-            out["cpu_baseline"] = cpu_baseline(nb, clb, infob, bb, yb, args.cpu_budget, args.steps)
+            yb = synth_y(nb, min(1024, B), 12, seed=1, offset=0, device=device)
+            out["cpu_baseline"] = cpu_baseline(args.workload, nb, clb, infob, bb, yb, args.cpu_budget, args.steps)
             bb.close()
         except Exception as e:  # the baseline is a reported extra; never lose the GPU line to it
             out["cpu_baseline"] = {"value": None, "error": repr(e)}

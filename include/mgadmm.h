@@ -146,6 +146,21 @@ int64_t mgadmm_solver_workspace_bytes(const mgadmm_solver* s);
 /* which path (MGADMM_PATH_STREAM / MGADMM_PATH_LDS) a batch of size B would take */
 int mgadmm_solver_path(const mgadmm_solver* s, int32_t B);
 
+/* Introspection of the execution plan a solver chose at create time (bench.py derives the LDS-traffic roofline of the
+ * fused kernel from it; tests assert the production geometry).  Unknown `what` -> MGADMM_ERR_INVALID. */
+typedef enum {
+    MGADMM_Q_LDS_OK = 0,        /* 1 when the LDS-resident fused path is available for this graph / dtype          */
+    MGADMM_Q_LDS_TPG = 1,       /* time steps per thread of k_admm_lds                                              */
+    MGADMM_Q_LDS_THREADS = 2,   /* active threads per workgroup (= N * T / TPG)                                     */
+    MGADMM_Q_LDS_BYTES = 3,     /* dynamic LDS bytes per workgroup                                                  */
+    MGADMM_Q_LDS_ROW_STRIDE = 4,/* floats between two nodes' time rows in LDS                                       */
+    MGADMM_Q_NNZ_U = 5,         /* stored entries of W_u, W_d, W_d^T                                                */
+    MGADMM_Q_NNZ_D = 6,
+    MGADMM_Q_NNZ_DT = 7,
+    MGADMM_Q_TILE_ROWS = 8      /* node rows per LDS tile of the streaming SpMM kernel (0: plain row kernel)        */
+} mgadmm_query_t;
+int mgadmm_solver_query(const mgadmm_solver* s, int32_t what, int64_t* out);
+
 /* apply_op_Lu / apply_op_Ldr / apply_op_Ldr_T / apply_op_cLdr (ADMM.py:138-228): y = op(x) */
 int mgadmm_apply(mgadmm_solver* s, int32_t op, const void* x, void* y, int32_t B, void* stream);
 /* LHS_x(x, mask) / LHS_zu / LHS_zd (ADMM.py:371-399); mask may be NULL */

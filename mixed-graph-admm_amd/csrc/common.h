@@ -32,12 +32,7 @@ void mg_set_error(const char* fmt, ...);
         if (rc_ != MGADMM_OK) return rc_;                                                      \
     } while (0)
 
-struct HostCsr {
-    int n = 0;
-    std::vector<int> rowptr, col;
-    std::vector<float> val;
-    int nnz() const { return (int)col.size(); }
-};
+#include "host_csr.h"
 
 struct DevCsr {
     int n = 0, nnz = 0, max_row = 0, avg_row_ceil = 0;
@@ -100,6 +95,7 @@ struct EngineBase {
     virtual int set_params(const mgadmm_params& p) = 0;
     virtual int64_t workspace_bytes() const = 0;
     virtual int path_for(int B) const = 0;
+    virtual int query(int what, int64_t* out) const = 0;
     virtual int apply(int op, const void* x, void* y, int B, hipStream_t st) = 0;
     virtual int lhs(int which, const void* x, const void* mask, void* y, int B, hipStream_t st) = 0;
     virtual int phi_direct(const void* x, const void* gamma, void* phi, int B, hipStream_t st) = 0;

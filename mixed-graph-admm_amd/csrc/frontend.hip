@@ -146,10 +146,24 @@ int series_stats(const S* x, int64_t n_steps, int n_cols, S* o_min, S* o_max, S*
 
 }  // namespace
 
+// The entry points below take raw device pointers and a stream but no device ordinal: make the device that owns
+// `series` current (a caller with several GPUs in one process may have another one selected).
+static int use_device_of(const void* ptr, const char* who) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        mg_set_error("%s: `series` is not a HIP device pointer", who);
+        return MGADMM_ERR_INVALID;
+    }
+    MG_HIP(hipSetDevice(at.device));
+    return MGADMM_OK;
+}
+
 extern "C" int mgadmm_series_stats(const void* series, int64_t n_steps, int32_t n_cols, int32_t dtype, void* o_min, void* o_max,
                                    void* o_mean, void* o_std, void* stream) {
     MG_REQUIRE(series && n_steps >= 1 && n_cols >= 1, "series_stats: bad arguments");
     MG_REQUIRE(!(o_std && n_steps < 2), "series_stats: the unbiased std needs at least 2 time steps");
+    MG_TRY(use_device_of(series, "series_stats"));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MGADMM_F64)
         return series_stats<double>((const double*)series, n_steps, n_cols, (double*)o_min, (double*)o_max, (double*)o_mean, (double*)o_std, st);
@@ -162,6 +176,7 @@ extern "C" int mgadmm_series_stats(const void* series, int64_t n_steps, int32_t 
 extern "C" int mgadmm_series_affine(void* series, int64_t n_steps, int32_t n_cols, int32_t dtype, const void* shift, const void* scale,
                                     const void* scale_lo, int32_t inverse, void* stream) {
     MG_REQUIRE(series && shift && scale && n_steps >= 1 && n_cols >= 1, "series_affine: bad arguments");
+    MG_TRY(use_device_of(series, "series_affine"));
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)n_steps * n_cols;
     const dim3 grid((unsigned)std::min<long>((total + 255) / 256, 8192));
@@ -184,6 +199,7 @@ extern "C" int mgadmm_gather_windows(const void* series, int64_t n_steps, int32_
     MG_REQUIRE(series && starts && out && n_steps >= 1 && n_cols >= 1 && B >= 1 && win >= 1, "gather_windows: bad arguments");
     MG_REQUIRE(win <= n_steps, "gather_windows: window of %d steps, series of %lld", win, (long long)n_steps);
     MG_REQUIRE(B <= 65535, "gather_windows: at most 65535 windows per call, got %d", B);
+    MG_TRY(use_device_of(series, "gather_windows"));
     hipStream_t st = (hipStream_t)stream;
     int* bad = nullptr;
     MG_HIP(hipMallocAsync((void**)&bad, sizeof(int), st));

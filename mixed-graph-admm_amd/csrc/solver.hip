@@ -28,6 +28,7 @@ enum VecId {
 constexpr int LAG = 2;          // CG iterations enqueued ahead of the host's convergence check
 constexpr int NRED_MAX = 6;
 constexpr int PROF_POOL = 32768;
+constexpr int NACT_LOG = 1 << 16;   // pinned log of the per-iteration active-sample counts (one int per CG iteration enqueued)
 
 template <typename S>
 struct Engine : EngineBase {
@@ -75,6 +76,10 @@ struct Engine : EngineBase {
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_tag;
     std::vector<double> prof_lb;   // algorithmic bytes of each timed launch
+    std::vector<int> prof_ref;     // h_nact index that tells whether the launch did work (-1: unconditional launch)
+    int prof_cur_ref = -1;         // set by cg_internal around the launches of one CG iteration
+    int nact_cur = 0;              // next free slot of the h_nact log
+    bool nact_locked = false;      // profiling session has used the whole log: later solves use the scratch tail
     int64_t prof_noop = 0;         // timed launches that returned at the converged-CG guard
     size_t prof_used = 0;
     int64_t prof_count[MGADMM_NPROF] = {0};
@@ -284,7 +289,8 @@ struct Engine : EngineBase {
             MG_HIP(hipMalloc(&d_nact, sizeof(int) * max_cg_alloc));
             MG_HIP(hipMalloc(&d_alpha_hist, sizeof(S) * 3 * (size_t)max_cg_alloc * Bp_max));
             MG_HIP(hipMalloc(&d_beta_hist, sizeof(S) * 3 * (size_t)max_cg_alloc * Bp_max));
-            MG_HIP(hipHostMalloc(&h_nact, sizeof(int) * max_cg_alloc));
+            MG_HIP(hipHostMalloc(&h_nact, sizeof(int) * (NACT_LOG + (size_t)max_cg_alloc)));
+            nact_cur = 0;
         }
         if (p.max_admm_iter > max_admm_alloc) {
             fr(d_hist); fr(d_dxps); fr(d_cg_iters);
@@ -311,6 +317,25 @@ struct Engine : EngineBase {
     int64_t workspace_bytes() const override { return ws_bytes; }
     int path_for(int) const override { return use_lds() ? MGADMM_PATH_LDS : MGADMM_PATH_STREAM; }
     bool use_lds() const { return lds.ok && p.path != MGADMM_PATH_STREAM; }
+    int query(int what, int64_t* out) const override {
+        switch (what) {
+            case MGADMM_Q_LDS_OK: *out = lds.ok ? 1 : 0; break;
+            case MGADMM_Q_LDS_TPG: *out = lds.TPG; break;
+            case MGADMM_Q_LDS_THREADS: *out = lds.nthreads; break;
+            case MGADMM_Q_LDS_BYTES: *out = (int64_t)lds.lds_bytes; break;
+            case MGADMM_Q_LDS_ROW_STRIDE: *out = lds.TS; break;
+            case MGADMM_Q_NNZ_U: *out = g->hWu.nnz(); break;
+            case MGADMM_Q_NNZ_D: *out = g->hWd.nnz(); break;
+            case MGADMM_Q_NNZ_DT: *out = g->hWdT.nnz(); break;
+            case MGADMM_Q_TILE_ROWS: {
+                TileGeom tg;
+                *out = make_tile_geom(make_geom(Bmax), tg) ? tg.R : 0;
+                break;
+            }
+            default: mg_set_error("solver_query: unknown item %d", what); return MGADMM_ERR_INVALID;
+        }
+        return MGADMM_OK;
+    }
 
     // ---------------------------------------------------------------- profiling
     int prof_begin() override {
@@ -320,8 +345,11 @@ struct Engine : EngineBase {
             for (auto& e : prof_ev) MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableSystemFence));   // timing only: no system-scope cache flush per record
             prof_tag.resize(PROF_POOL);
             prof_lb.resize(PROF_POOL);
+            prof_ref.resize(PROF_POOL);
         }
         prof_used = 0;
+        nact_cur = 0;
+        nact_locked = false;
         for (int i = 0; i < MGADMM_NPROF; ++i) { prof_count[i] = 0; prof_bytes[i] = 0; }
         prof_on = true;
         return MGADMM_OK;
@@ -335,11 +363,12 @@ struct Engine : EngineBase {
         for (size_t i = 0; i < prof_used; ++i) {
             float f = 0;
             MG_HIP(hipEventElapsedTime(&f, prof_ev[2 * i], prof_ev[2 * i + 1]));
-            // A speculative CG launch that found its solve converged returns at the `live` guard after a few
-            // microseconds without touching its operands.  Such a launch cannot have moved its algorithmic
-            // bytes (the rate would be > 3x the HBM peak): it is left out of BOTH the bytes and the time, so the
-            // reported rates are those of launches that did the work.
-            if (prof_lb[i] > 0.0 && (double)f * 1e-3 < prof_lb[i] / 24.0e12) {
+            // A speculative CG launch of iteration k+1 that found every sample converged after iteration k returns
+            // at its `live` guard without touching its operands.  Whether that happened is read from the log of
+            // active-sample counts the host copies back for its own convergence check (h_nact), not guessed from
+            // the duration: such a launch is left out of BOTH the bytes and the time, so the reported rates are
+            // those of launches that did the work.
+            if (prof_ref[i] >= 0 && h_nact[prof_ref[i]] == 0) {
                 prof_noop++;
                 continue;
             }
@@ -361,6 +390,7 @@ struct Engine : EngineBase {
         if (tag == 3 || prof_used >= (size_t)PROF_POOL) return false;
         prof_tag[prof_used] = tag;
         prof_lb[prof_used] = bytes;
+        prof_ref[prof_used] = prof_cur_ref;
         (void)hipEventRecord(prof_ev[2 * prof_used], st);
         return true;
     }
@@ -380,6 +410,16 @@ struct Engine : EngineBase {
     }
 
     // ---------------------------------------------------------------- launch helpers
+    // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: remember which (kernel, device)
+    // pairs have been raised -- one solver per GPU may live in the same process.
+    std::vector<const void*> lds_attr_done;
+    int allow_dynamic_lds(const void* fn, int bytes) {
+        for (const void* f : lds_attr_done)
+            if (f == fn) return MGADMM_OK;
+        MG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        lds_attr_done.push_back(fn);
+        return MGADMM_OK;
+    }
     template <class E, class = void>
     struct is_elementwise : std::false_type {};
     template <class E>
@@ -393,11 +433,7 @@ struct Engine : EngineBase {
     template <int VEC, class Epi, int TGW, int MR>
     int launch_tile2(const TileGeom& tg, const OpDesc& op, const TileMeta& tmv, const S* in, const Epi& epi, const int* live) {
         auto fn = k_tile<S, VEC, Epi, TGW, MR>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            MG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-            attr_set = true;
-        }
+        MG_TRY(allow_dynamic_lds((const void*)fn, 80 * 1024));
         hipLaunchKernelGGL(fn, dim3(tg.grid), dim3(256), tg.lds_bytes, st, tg, op, tmv.tl_col, tmv.tl_w, tmv.halo, tmv.h_rowptr,
                            tmv.h_col, tmv.h_val, in, epi, partials, live);
         return MGADMM_OK;
@@ -563,21 +599,30 @@ struct Engine : EngineBase {
                                    p.t_in, (S)d.c1, (S)0));
         }
         MG_TRY((reduce<1>(q, FinCgInit<S>{c, q.B}, nullptr)));
+        // slice of the pinned h_nact log used by this solve (a profiling session keeps every slice until prof_end)
+        if (nact_cur + K > NACT_LOG) {
+            if (prof_on) nact_locked = true;
+            else nact_cur = 0;
+        }
+        const int base = nact_locked ? NACT_LOG : nact_cur;
         int k = 0;
         for (; k < K; ++k) {
             const int* live = k == 0 ? nullptr : d_nact + (k - 1);
+            prof_cur_ref = (k == 0 || nact_locked) ? -1 : base + k - 1;
             MG_TRY(lhs_apply(q, d, pp, nullptr, Ap, live));                  // Ap = A p (no mask: quirk Q2)
             MG_TRY((reduce<1>(q, FinCgAlpha<S>{c, k, q.Bp}, live)));
             MG_TRY(rows<EpiCgUpdate>(q, op_none(), Ap, live, 1, 3, (const S*)d_alpha, r));                 // r -= alpha Ap, r.r
             MG_TRY((reduce<1>(q, FinCgBeta<S>{c, k, q.Bp, p.cg_tol}, live)));
             MG_TRY(rows<EpiPUpdate>(q, op_none(), r, live, 1, 5, (const S*)d_alpha, (const S*)d_beta, xout, pp));   // x += alpha p, p = r + beta p
-            MG_HIP(hipMemcpyAsync(h_nact + k, d_nact + k, sizeof(int), hipMemcpyDeviceToHost, st));
+            prof_cur_ref = -1;
+            MG_HIP(hipMemcpyAsync(h_nact + base + k, d_nact + k, sizeof(int), hipMemcpyDeviceToHost, st));
             MG_HIP(hipEventRecord(ev_ring[k % (LAG + 1)], st));
             if (k >= LAG) {
                 MG_HIP(hipEventSynchronize(ev_ring[(k - LAG) % (LAG + 1)]));
-                if (h_nact[k - LAG] == 0) { ++k; break; }
+                if (h_nact[base + k - LAG] == 0) { ++k; break; }
             }
         }
+        if (!nact_locked) nact_cur += std::min(k, K);
         if (n_iter_launched) *n_iter_launched = k;
         return MGADMM_OK;
     }
@@ -928,11 +973,7 @@ struct Engine : EngineBase {
     template <int TPG, bool BAND>
     int launch_lds2(const LdsArgs& a, int B) {
         auto fn = k_admm_lds<TPG, BAND>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            MG_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        MG_TRY(allow_dynamic_lds((const void*)fn, 160 * 1024));
         const bool timed = prof_open(0, 0.0);
         hipLaunchKernelGGL(fn, dim3(B), dim3(lds.block), lds.lds_bytes, st, a);
         if (timed) prof_close();
@@ -1154,6 +1195,11 @@ int mgadmm_solver_set_params(mgadmm_solver* s, const mgadmm_params* p) {
 
 int64_t mgadmm_solver_workspace_bytes(const mgadmm_solver* s) { return s ? s->eng->workspace_bytes() : 0; }
 int mgadmm_solver_path(const mgadmm_solver* s, int32_t B) { return s ? s->eng->path_for(B) : MGADMM_ERR_INVALID; }
+
+int mgadmm_solver_query(const mgadmm_solver* s, int32_t what, int64_t* out) {
+    MG_REQUIRE(s && out, "solver_query: null argument");
+    return s->eng->query(what, out);
+}
 
 int mgadmm_apply(mgadmm_solver* s, int32_t op, const void* x, void* y, int32_t B, void* stream) {
     MG_REQUIRE(s, "apply: null solver");

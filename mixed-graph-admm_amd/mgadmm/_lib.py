@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgadmm.so")
+# MGADMM_LIB selects another build of the same library (kernel experiments with different compiler flags)
+LIB_PATH = os.environ.get("MGADMM_LIB") or os.path.join(_HERE, "libmgadmm.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_NONFINITE, ERR_UNSUPPORTED, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 F32, F64 = 0, 1
@@ -25,6 +26,7 @@ NMETRIC = 11
 (M_XSHIFT, M_PRI_ZU, M_DUAL_ZU, M_PRI_PHI, M_DUAL_PHI, M_PRI_ZD, M_DUAL_ZD, M_GLR, M_DGTV, M_DGLR,
  M_RECOVER) = range(11)
 NPROF = 4
+(Q_LDS_OK, Q_LDS_TPG, Q_LDS_THREADS, Q_LDS_BYTES, Q_LDS_ROW_STRIDE, Q_NNZ_U, Q_NNZ_D, Q_NNZ_DT, Q_TILE_ROWS) = range(9)
 
 _i32p = C.POINTER(C.c_int32)
 _f32p = C.POINTER(C.c_float)
@@ -82,6 +84,7 @@ SYMBOLS = {
     "mgadmm_solver_set_params": (C.c_int, [_vp, C.POINTER(Params)]),
     "mgadmm_solver_workspace_bytes": (C.c_int64, [_vp]),
     "mgadmm_solver_path": (C.c_int, [_vp, C.c_int32]),
+    "mgadmm_solver_query": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
     "mgadmm_apply": (C.c_int, [_vp, C.c_int32, _vp, _vp, C.c_int32, _vp]),
     "mgadmm_lhs": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp]),
     "mgadmm_phi_direct": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int32, _vp]),
@@ -130,3 +133,9 @@ def check(rc):
 
 def version():
     return lib.mgadmm_version().decode()
+
+
+def query(handle, what):
+    out = C.c_int64()
+    check(lib.mgadmm_solver_query(handle, what, C.byref(out)))
+    return int(out.value)

@@ -44,12 +44,17 @@ def has_gpu():
 
 
 def _ensure_built():
-    """The product package cannot be imported without libmgadmm.so; build it in-tree if missing
-    (hipcc cross-compiles gfx950 without a GPU)."""
+    """The product package cannot be imported without libmgadmm.so.  `make` is run whenever hipcc is present (a no-op when
+    the library is newer than every source; hipcc cross-compiles gfx950 without a GPU), so the tests never run against a
+    binary built from older sources than the tree."""
+    import shutil
+    import subprocess
     so = os.path.join(PKG, "mgadmm", "libmgadmm.so")
-    if not os.path.exists(so):
-        import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(PKG, "csrc")])
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if os.path.exists(hipcc):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "csrc"), f"HIPCC={hipcc}"])
+    elif not os.path.exists(so):
+        raise RuntimeError(f"{so} is missing and hipcc was not found: build it with `make -C mixed-graph-admm_amd/csrc`")
 
 
 _ensure_built()
