@@ -44,12 +44,19 @@ typedef enum {
 } mgadmm_temporal_mode_t;
 
 /* apply_op_Lu / apply_op_Ldr / apply_op_Ldr_T / apply_op_cLdr : ADMM.py:138-228 */
-typedef enum { MGADMM_OP_LU = 0, MGADMM_OP_LDR = 1, MGADMM_OP_LDRT = 2, MGADMM_OP_CLDR = 3 } mgadmm_op_t;
+/* MGADMM_OP_LN: apply_op_Ln, the undirected temporal Laplacian (ADMM.py:248-288; unreachable from the reference's solver) */
+typedef enum { MGADMM_OP_LU = 0, MGADMM_OP_LDR = 1, MGADMM_OP_LDRT = 2, MGADMM_OP_CLDR = 3, MGADMM_OP_LN = 4 } mgadmm_op_t;
 /* LHS_x / LHS_zu / LHS_zd : ADMM.py:371-399 */
 typedef enum { MGADMM_LHS_X = 0, MGADMM_LHS_ZU = 1, MGADMM_LHS_ZD = 2 } mgadmm_lhs_t;
 /* ablation strings of ADMM.py:31-32, in this order: 'None', 'DGTV', 'DGLR', 'UT' */
 typedef enum { MGADMM_ABL_NONE = 0, MGADMM_ABL_DGTV = 1, MGADMM_ABL_DGLR = 2, MGADMM_ABL_UT = 3 } mgadmm_ablation_t;
 typedef enum { MGADMM_PATH_AUTO = 0, MGADMM_PATH_STREAM = 1, MGADMM_PATH_LDS = 2 } mgadmm_path_t;
+/* When a batched CG solve stops.
+ *   PER_SAMPLE  every sample stops on its own residual: B samples = B independent B=1 reference runs (default; the only
+ *               batched semantics the reference can be run for, since it crashes for B > 1, ADMM.py:362)
+ *   BATCH_MAX   the reference's literal test sqrt(rr).max() < CG_tol (ADMM.py:360): every sample keeps iterating until the
+ *               largest residual of the batch is below the tolerance; one iteration count per solve.  Streaming path only. */
+typedef enum { MGADMM_CG_PER_SAMPLE = 0, MGADMM_CG_BATCH_MAX = 1 } mgadmm_cg_convergence_t;
 
 /* Number of per-iteration scalar diagnostics (order below) : ADMM.py:609-637 */
 #define MGADMM_NMETRIC 11
@@ -103,6 +110,8 @@ typedef struct {
     int32_t check_stop;          /* 1: test ADMM_tol every iteration (ADMM.py:645-646); 0: run max_admm_iter */
     int32_t path;                /* mgadmm_path_t */
     int32_t record_cg_coeffs;    /* 1: keep alpha/beta of every CG iteration (alpha_x ... beta_zd lists) */
+    int32_t cg_convergence;      /* mgadmm_cg_convergence_t */
+    int32_t max_inner_iter;      /* max_inner_iter = 100: inner iterations of mgadmm_two_loops (ADMM.py:77, 448) */
 } mgadmm_params;
 
 /* Host buffers for the residual history; any pointer may be NULL.  Filled by mgadmm_solve. */
@@ -116,7 +125,9 @@ typedef struct {
     double* cg_beta;             /* same shape */
 } mgadmm_history;
 
-/* Optional device outputs of the final state (API layout (B,T,N), solver dtype); NULL = skip. */
+/* Device tensors of the ADMM state (API layout (B,T,N), solver dtype).  As the `state_out` of a solve: optional outputs,
+ * NULL = skip.  As the `state_in` of mgadmm_solve_from: every field the ablation uses is required (phi / gamma unless
+ * 'DGTV'/'UT', zd / gamma_d unless 'DGLR'). */
 typedef struct {
     void* zu; void* zd; void* phi; void* gamma; void* gamma_u; void* gamma_d;
 } mgadmm_state;
@@ -182,6 +193,20 @@ int mgadmm_cg(mgadmm_solver* s, int32_t which, const void* rhs, const void* x0, 
  * Interpolation: y and mask are (B, T, N).  x_out is (B, T, N).  Synchronous. */
 int mgadmm_solve(mgadmm_solver* s, const void* y, const void* mask, int32_t mask_is_f32, int32_t B, void* x_out,
                  const mgadmm_state* state_out, mgadmm_history* hist, void* stream);
+
+/* Warm start / resume (checkpoint row): the loop of mgadmm_solve started from a saved state
+ * (x0, state_in) instead of the initial guess and constants of ADMM.py:529-544.  k1 iterations, state_out -> state_in,
+ * k2 more iterations reproduce k1 + k2 iterations of one solve bit for bit.  Synchronous. */
+int mgadmm_solve_from(mgadmm_solver* s, const void* y, const void* mask, int32_t mask_is_f32, int32_t B, const void* x0,
+                      const mgadmm_state* state_in, void* x_out, const mgadmm_state* state_out, mgadmm_history* hist,
+                      void* stream);
+/* two_loops(y, mask) (ADMM.py:410-508): max_admm_iter outer phi / gamma updates around max_inner_iter inner
+ * (x, zu, zd, gamma_u, gamma_d) updates restarted from zu = zd = x, gamma_u = gamma_d = 0.1.  The reference returns
+ * None and records only CG counts; here x_out / state_out receive the final state.  hist: n_iters = outer iterations,
+ * cg_iters = [max_admm_iter * max_inner_iter][3][B]; the other history fields are not written.  Streaming path.
+ * Synchronous. */
+int mgadmm_two_loops(mgadmm_solver* s, const void* y, const void* mask, int32_t mask_is_f32, int32_t B, void* x_out,
+                     const mgadmm_state* state_out, mgadmm_history* hist, void* stream);
 
 /* ---- graph construction on the GPU; host buffers in and out, synchronous ------------------
  * k_nearest_neighbors(n_nodes, edges, dists, k) (utils.py:183-204): the k+1 nearest nodes of every node by

@@ -43,7 +43,7 @@ struct DevCsr {
 
 // How a row-operator is evaluated by the row kernels (see k_rows in stream_kernels.h).
 enum OpKind { OPK_NONE = 0, OPK_SPATIAL = 1, OPK_BAND = 2 };
-enum SelfMode { SELF_ONE = 0, SELF_LDR = 1, SELF_LDRT = 2 };
+enum SelfMode { SELF_ONE = 0, SELF_LDR = 1, SELF_LDRT = 2, SELF_LN_FATHER = 3 };   // LN_FATHER: 1 for t <= T-2, else 0
 
 struct OpDesc {
     int kind;             // OpKind
@@ -56,6 +56,7 @@ struct OpDesc {
     int band_dir;         // BAND: -1 = Ldr (looks back), +1 = Ldr_T (looks forward)
     int self_mode;        // SelfMode
     int q1;               // SELF_LDRT: keep the identity on the t=0 block (quirk Q1)
+    const double* self_w; // optional per-row factor of the self coefficient (apply_op_Ln: row sums of d_ew); plain row kernel only
 };
 
 struct mgadmm_graph {
@@ -65,8 +66,10 @@ struct mgadmm_graph {
     int reorder = 0;              // 0 none, 1 RCM, 2 greedy cluster order (enables the LDS-tiled row kernel)
     HostCsr hWu, hWd, hWdT;       // API node order (hWdT: exact transpose, or hWd when transpose_by_gather)
     std::vector<int> perm, iperm;  // perm[i] = API node at internal row i; iperm = inverse
+    std::vector<int> cluster_starts;  // reorder = 2: first internal row of every cluster of the node order
     DevCsr Wu, Wd, WdT;            // internal node order, device
     float* band_w = nullptr;       // device
+    double* ln_rowsum = nullptr;   // device, internal order: sum_j d_ew[i,j] (self coefficient of apply_op_Ln), built on first use
     int* d_perm = nullptr;         // device (nullptr when identity)
     int max_row_all = 0;
 
@@ -78,7 +81,7 @@ struct mgadmm_graph {
 // graph.hip
 int mg_transpose_csr(const HostCsr& A, HostCsr& At);
 int mg_rcm_order(const HostCsr& A, const HostCsr* B, std::vector<int>& perm);
-int mg_cluster_order(const HostCsr& A, const HostCsr* B, int csize, std::vector<int>& perm);
+int mg_cluster_order(const HostCsr& A, const HostCsr* B, int csize, std::vector<int>& perm, std::vector<int>* starts = nullptr);
 int mg_permute_csr(const HostCsr& A, const std::vector<int>& perm, const std::vector<int>& iperm, HostCsr& out);
 
 struct EngineBase;
@@ -104,8 +107,10 @@ struct EngineBase {
                                       hipStream_t st) = 0;
     virtual int cg(int which, const void* rhs, const void* x0, const void* mask, void* x, int32_t* iters,
                    double* alpha, double* beta, int B, hipStream_t st) = 0;
-    virtual int solve(const void* y, const void* mask, int mask_f32, int B, void* x_out,
-                      const mgadmm_state* state_out, mgadmm_history* hist, hipStream_t st) = 0;
+    virtual int solve(const void* y, const void* mask, int mask_f32, int B, const void* x0, const mgadmm_state* state_in,
+                      void* x_out, const mgadmm_state* state_out, mgadmm_history* hist, hipStream_t st) = 0;
+    virtual int two_loops(const void* y, const void* mask, int mask_f32, int B, void* x_out, const mgadmm_state* state_out,
+                          mgadmm_history* hist, hipStream_t st) = 0;
     virtual int prof_begin() = 0;
     virtual int prof_end(int64_t* counts, double* total_ms, double* bytes) = 0;
 };

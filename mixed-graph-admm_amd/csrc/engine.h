@@ -1,5 +1,7 @@
-// Solver engine: host-side orchestration of the ADMM loop of reference ADMM.py:511-648 over the
-// streaming HIP kernels (stream_kernels.h), plus the C ABI of include/mgadmm.h.
+// Solver engine: host-side orchestration of the ADMM loop of reference ADMM.py:511-648 over the streaming HIP kernels
+// (stream_kernels.h) and the LDS-resident fused kernel (lds_launch.hip).  Included by solver_f32.hip and solver_f64.hip,
+// which instantiate it for one scalar type each (separate translation units: the library builds in parallel).
+#pragma once
 #include <math.h>
 #include <cmath>
 #include <stdlib.h>
@@ -9,8 +11,9 @@
 #include <type_traits>
 
 #include "common.h"
+#include "cldr_tiles.h"
 #include "stream_kernels.h"
-#include "lds_kernels.h"
+#include "lds_args.h"
 
 namespace {
 
@@ -59,13 +62,22 @@ struct Engine : EngineBase {
     int want_blocks = 2048;
     struct TileMetaDev { int R = 0; int GW = 0; int* tl_col = nullptr; float* tl_w = nullptr; int* halo = nullptr; int* h_rowptr = nullptr; int* h_col = nullptr; float* h_val = nullptr; };
     TileMetaDev tmeta[3];         // W_u, W_d, W_d^T metadata for the tile size in use
+    // fused cLdr kernel (k_cldr): tile tables for the geometry in use; state 0 = not built yet, 1 = usable, -1 = the graph
+    // does not fit its slot counts (hub rows): the two-pass form stays
+    struct CldrDev {
+        int state = 0, NT = 0;
+        int *n0 = nullptr, *nC = nullptr, *rows = nullptr, *dcol = nullptr, *dcnt = nullptr, *tcol = nullptr, *tcnt = nullptr;
+        float *dw = nullptr, *tw = nullptr;
+    } cldr_dev;
+    int use_fused = 1;            // MGADMM_FUSED=0 keeps the two-pass cLdr (tests compare the two)
+    int cldr_tile_major = 1;      // MGADMM_CLDR_ORDER=0: chunks of a tile adjacent in dispatch order
     int cur_P = 0;                // partial rows written by the last row-kernel launch (k_rows or k_tile)
     int use_tile = 1;             // LDS-tiled spatial kernel on cluster-ordered graphs (reorder = 2); MGADMM_TILE=0 disables
     int64_t ws_bytes = 0;
     // LDS-resident fused path (float32, small graphs)
     struct LdsPlan {
         bool ok = false;
-        int G = 0, TPG = 0, TS = 0, nthreads = 0, block = 0, csr_ints = 0;
+        int G = 0, TPG = 0, TS = 0, nthreads = 0, block = 0, csr_ints = 0, maxt = 1024, sb = 0;
         int off_rp_u = 0, off_rp_d = 0, off_rp_t = 0, off_en_u = 0, off_en_d = 0, off_en_t = 0;
         size_t lds_bytes = 0;
     } lds;
@@ -94,6 +106,8 @@ struct Engine : EngineBase {
         fr(d_active); fr(d_iters_tmp); fr(d_nact); fr(d_nonfinite); fr(d_ps); fr(d_hist); fr(d_dxps);
         fr(d_dxpart); fr(d_hist_ps); fr(d_cg_iters); fr(d_lds_csr); fr(d_m2);
         for (auto& tmd : tmeta) { fr(tmd.tl_col); fr(tmd.tl_w); fr(tmd.halo); fr(tmd.h_rowptr); fr(tmd.h_col); fr(tmd.h_val); }
+        fr(cldr_dev.n0); fr(cldr_dev.nC); fr(cldr_dev.rows); fr(cldr_dev.dcol); fr(cldr_dev.dcnt); fr(cldr_dev.tcol); fr(cldr_dev.tcnt);
+        fr(cldr_dev.dw); fr(cldr_dev.tw);
         if (h_nact) (void)hipHostFree(h_nact);
         if (h_row) (void)hipHostFree(h_row);
         if (h_flag) (void)hipHostFree(h_flag);
@@ -235,9 +249,122 @@ struct Engine : EngineBase {
         return MGADMM_OK;
     }
 
+    // ---------------------------------------------------------------- fused cLdr kernel (k_cldr)
+    // Tile geometries (VECT columns per lane, NW waves, rows per wave of the tile / of C1 / of C2).  LDS per workgroup =
+    // NW * (MQ + MP) * 64 * VECT * sizeof(S).  MGADMM_CLDR_GEOM selects one (experiments); default per scalar type below.
+    template <int VECT_, int NW_, int MA_, int MQ_, int MP_>
+    struct ClG { static constexpr int VECT = VECT_, NW = NW_, MA = MA_, MQ = MQ_, MP = MP_; };
+    typedef ClG<4, 8, 2, 4, 5> ClG0;     // 16 / 32 / 40 rows of 256 columns: 72 KiB (float), two workgroups per CU
+    typedef ClG<2, 8, 4, 8, 10> ClG1;    // 32 / 64 / 80 rows of 128 columns: 72 KiB (float)
+    typedef ClG<1, 8, 8, 11, 15> ClG2;   // 64 / 88 / 120 rows of 64 columns: 52 KiB (float), three workgroups per CU
+    typedef ClG<4, 16, 2, 3, 5> ClG3;    // 32 / 48 / 80 rows of 256 columns, 16 waves: 128 KiB (float), one workgroup per CU
+    static constexpr int CL_GD = 8, CL_GT = 12;
+    int cl_geom = sizeof(S) == 4 ? 0 : 2;   // float64: the narrow geometry (104 KiB)
+    void cl_dims(int& vect, int& nw, int& ma, int& mq, int& mp) const {
+        switch (cl_geom) {
+            case 0: vect = ClG0::VECT; nw = ClG0::NW; ma = ClG0::MA; mq = ClG0::MQ; mp = ClG0::MP; break;
+            case 1: vect = ClG1::VECT; nw = ClG1::NW; ma = ClG1::MA; mq = ClG1::MQ; mp = ClG1::MP; break;
+            case 3: vect = ClG3::VECT; nw = ClG3::NW; ma = ClG3::MA; mq = ClG3::MQ; mp = ClG3::MP; break;
+            default: vect = ClG2::VECT; nw = ClG2::NW; ma = ClG2::MA; mq = ClG2::MQ; mp = ClG2::MP; break;
+        }
+    }
+    bool cldr_usable() {
+        if (!use_fused || !use_tile || g->reorder < 2 || g->mode != MGADMM_TEMPORAL_SPATIAL) return false;
+        if (cldr_dev.state == 0) cldr_prepare();
+        return cldr_dev.state == 1;
+    }
+    void cldr_prepare() {
+        cldr_dev.state = -1;
+        if (const char* e = getenv("MGADMM_CLDR_GEOM")) { const int v = atoi(e); if (v >= 0 && v <= 3) cl_geom = v; }
+        int vect, nw, ma, mq, mp;
+        cl_dims(vect, nw, ma, mq, mp);
+        if ((size_t)nw * (mq + mp) * 64 * vect * sizeof(S) > 150 * 1024) { cl_geom = 2; cl_dims(vect, nw, ma, mq, mp); }
+        HostCsr A, At;
+        if (g->has_perm) { mg_permute_csr(g->hWd, g->perm, g->iperm, A); mg_permute_csr(g->hWdT, g->perm, g->iperm, At); }
+        else { A = g->hWd; At = g->hWdT; }
+        CldrCaps caps{nw * ma, nw * mq, nw * mp, CL_GD, CL_GT};
+        CldrTiles tl;
+        if (!build_cldr_tiles(A, At, g->cluster_starts, caps, tl)) return;
+        if (getenv("MGADMM_TILE_STATS"))
+            fprintf(stderr, "[mgadmm] cldr tiles (geometry %d): %d tiles, rows/tile %.1f, |C1| %.1f, |C2| %.1f (caps %d/%d/%d): reads %.2fx, q recomputed %.2fx\n",
+                    cl_geom, tl.NT, (double)N / tl.NT, (double)tl.sumC1 / tl.NT, (double)tl.sumC2 / tl.NT, caps.Rcap, caps.C1cap, caps.C2cap,
+                    (double)tl.sumC2 / N, (double)tl.sumC1 / N);
+        std::vector<int> nC((size_t)2 * tl.NT);
+        for (int t = 0; t < tl.NT; ++t) { nC[2 * t] = tl.nC1[t]; nC[2 * t + 1] = tl.nC2[t]; }
+        auto up = [&](auto*& dst, const auto& v) -> bool {
+            typedef typename std::remove_reference<decltype(*dst)>::type E;
+            if (hipMalloc(&dst, std::max<size_t>(1, v.size()) * sizeof(E)) != hipSuccess) return false;
+            return v.empty() || hipMemcpy(dst, v.data(), v.size() * sizeof(E), hipMemcpyHostToDevice) == hipSuccess;
+        };
+        if (!(up(cldr_dev.n0, tl.n0) && up(cldr_dev.nC, nC) && up(cldr_dev.rows, tl.rows) && up(cldr_dev.dcol, tl.dcol) &&
+              up(cldr_dev.dw, tl.dw) && up(cldr_dev.dcnt, tl.dcnt) && up(cldr_dev.tcol, tl.tcol) && up(cldr_dev.tw, tl.tw) &&
+              up(cldr_dev.tcnt, tl.tcnt))) {
+            (void)hipGetLastError();
+            return;
+        }
+        cldr_dev.NT = tl.NT;
+        cldr_dev.state = 1;
+    }
+    CldrGeom make_cldr_geom(const Geom& q) const {
+        int vect, nw, ma, mq, mp;
+        cl_dims(vect, nw, ma, mq, mp);
+        CldrGeom cg;
+        cg.T = T; cg.N = N; cg.B = q.B; cg.Bp = q.Bp;
+        while (q.Bp % (64 * vect)) vect /= 2;              // never happens: Bp is padded to the solver's own vector width
+        cg.CH = q.Bp / (64 * vect);
+        cg.NT = cldr_dev.NT;
+        cg.TPX = (cg.NT + 7) / 8;
+        cg.P = 8 * cg.TPX;
+        cg.grid = cg.P * cg.CH;
+        cg.tile_major = cldr_tile_major;
+        cg.q1 = g->q1;
+        cg.lds_bytes = (int)((size_t)nw * (mp + mq) * 64 * vect * sizeof(S));
+        return cg;
+    }
+    // the fused kernel needs Bp to be a multiple of its own chunk width
+    bool cldr_fits(const Geom& q) {
+        if (!cldr_usable()) return false;
+        int vect, nw, ma, mq, mp;
+        cl_dims(vect, nw, ma, mq, mp);
+        return q.Bp % (64 * vect) == 0 && (sizeof(S) == 4 || vect <= 2);
+    }
+    template <class G, template <typename, int> class E, class... A>
+    int rows_cldr_g(const Geom& q, const S* in, const int* live, A... a) {
+        const CldrGeom cg = make_cldr_geom(q);
+        CldrMeta mm{cldr_dev.n0, cldr_dev.nC, cldr_dev.rows, cldr_dev.dcol, cldr_dev.dw, cldr_dev.dcnt, cldr_dev.tcol, cldr_dev.tw, cldr_dev.tcnt};
+        typedef E<S, G::VECT> Epi;
+        auto fn = k_cldr<S, G::VECT, Epi, G::NW, G::MA, G::MQ, G::MP, CL_GD, CL_GT>;
+        MG_TRY(allow_dynamic_lds((const void*)fn, 150 * 1024));
+        hipLaunchKernelGGL(fn, dim3(cg.grid), dim3(G::NW * 64), cg.lds_bytes, st, cg, mm, in, Epi{a...}, partials, live);
+        cur_P = cg.P;
+        return MGADMM_OK;
+    }
+    // in -> epilogue(l = Ldr^T Ldr in); `passes`: algorithmic vector passes of the launch for the roofline accounting
+    template <template <typename, int> class E, class... A>
+    int rows_cldr(const Geom& q, const S* in, const int* live, int tag, int passes, A... a) {
+        const double bytes = pass_bytes(q, passes) + csr_bytes(g->op_ldr()) + csr_bytes(g->op_ldrt());
+        const bool timed = prof_open(tag, bytes);
+        int rc;
+        if constexpr (sizeof(S) == 4) {
+            switch (cl_geom) {
+                case 0: rc = rows_cldr_g<ClG0, E>(q, in, live, a...); break;
+                case 1: rc = rows_cldr_g<ClG1, E>(q, in, live, a...); break;
+                case 3: rc = rows_cldr_g<ClG3, E>(q, in, live, a...); break;
+                default: rc = rows_cldr_g<ClG2, E>(q, in, live, a...); break;
+            }
+        } else {
+            rc = rows_cldr_g<ClG2, E>(q, in, live, a...);
+        }
+        if (timed) prof_close();
+        MG_TRY(rc);
+        MG_HIP(hipGetLastError());
+        return MGADMM_OK;
+    }
+
     int ensure_partials(const Geom& q) {
         TileGeom tg;
-        const int pmax = make_tile_geom(q, tg) ? std::max(q.P, tg.P) : q.P;
+        int pmax = make_tile_geom(q, tg) ? std::max(q.P, tg.P) : q.P;
+        if (cldr_fits(q)) pmax = std::max(pmax, make_cldr_geom(q).P);
         size_t need = (size_t)NRED_MAX * pmax * q.Bp;
         if (need <= partials_elems) return MGADMM_OK;
         MG_HIP(hipStreamSynchronize(st));
@@ -253,6 +380,8 @@ struct Engine : EngineBase {
         MG_HIP(hipSetDevice(g->device));
         if (const char* e = getenv("MGADMM_WANT_BLOCKS")) want_blocks = std::max(64, atoi(e));
         if (const char* e = getenv("MGADMM_TILE")) use_tile = atoi(e);
+        if (const char* e = getenv("MGADMM_FUSED")) use_fused = atoi(e);
+        if (const char* e = getenv("MGADMM_CLDR_ORDER")) cldr_tile_major = atoi(e);
         Geom q = make_geom(Bmax);
         Bp_max = q.Bp;
         // Bp for smaller batches never exceeds Bp_max rounded to 256
@@ -316,7 +445,8 @@ struct Engine : EngineBase {
 
     int64_t workspace_bytes() const override { return ws_bytes; }
     int path_for(int) const override { return use_lds() ? MGADMM_PATH_LDS : MGADMM_PATH_STREAM; }
-    bool use_lds() const { return lds.ok && p.path != MGADMM_PATH_STREAM; }
+    // the fused LDS kernel runs one sample per workgroup with its CG loops inside: a batch-global stop cannot be expressed there
+    bool use_lds() const { return lds.ok && p.path != MGADMM_PATH_STREAM && p.cg_convergence == MGADMM_CG_PER_SAMPLE; }
     int query(int what, int64_t* out) const override {
         switch (what) {
             case MGADMM_Q_LDS_OK: *out = lds.ok ? 1 : 0; break;
@@ -443,7 +573,7 @@ struct Engine : EngineBase {
     int rows_v(const Geom& q, const OpDesc& op, const S* in, const Epi& epi, const int* live, int tag, double bytes) {
         const bool timed = prof_open(tag, bytes);
         TileGeom tg;
-        if (op.kind == OPK_SPATIAL && make_tile_geom(q, tg)) {
+        if (op.kind == OPK_SPATIAL && op.self_w == nullptr && make_tile_geom(q, tg)) {
             if constexpr (is_elementwise<Epi>::value) {
                 mg_set_error("rows: element-wise epilogue launched with a spatial operator");
                 return MGADMM_ERR_INVALID;
@@ -555,13 +685,43 @@ struct Engine : EngineBase {
         return rows<EpiStore>(q, op, in, nullptr, tag, 2, out);
     }
     int cldr(const Geom& q, const S* in, S* out) {
+        if (cldr_fits(q)) return rows_cldr<EpiStore>(q, in, nullptr, 2, 4, out);
         MG_TRY(op_store(q, g->op_ldr(), in, vec[V_Q]));
         return op_store(q, g->op_ldrt(), vec[V_Q], out);
+    }
+
+    // apply_op_Ln (ADMM.py:248-288): y[t] = [t>=1](s x[t] - W_d x[t-1]) + [t<=T-2](s x[t] - M x[t+1]), s_i = sum_j d_ew[i,j],
+    // M = W_d^T (kNN: scatter_add) or W_d (physical: gather); line graph: x[t] - x[t+-1]/sqrt(2)
+    int op_ln(const Geom& q, const S* in, S* out) {
+        if (g->mode == MGADMM_TEMPORAL_BAND)
+            return rows<EpiLnLine>(q, op_none(), in, nullptr, 2, 2, in, out, T, (size_t)N * q.Bp);
+        if (!g->ln_rowsum) {
+            std::vector<double> rs(N);
+            for (int r = 0; r < N; ++r) {
+                const int i = g->has_perm ? g->perm[r] : r;
+                double a = 0.0;
+                for (int e = g->hWd.rowptr[i]; e < g->hWd.rowptr[i + 1]; ++e) a += (double)g->hWd.val[e];
+                rs[r] = a;
+            }
+            MG_HIP(hipMalloc(&g->ln_rowsum, sizeof(double) * N));
+            MG_HIP(hipMemcpy(g->ln_rowsum, rs.data(), sizeof(double) * N, hipMemcpyHostToDevice));
+        }
+        OpDesc child = g->op_ldr();
+        child.self_w = g->ln_rowsum;
+        OpDesc father = g->op_ldrt();
+        father.self_mode = SELF_LN_FATHER;
+        father.q1 = 0;
+        father.self_w = g->ln_rowsum;
+        MG_TRY(rows<EpiStore>(q, child, in, nullptr, 2, 2, vec[V_Q]));
+        return rows<EpiAddTo>(q, father, in, nullptr, 2, 3, (const S*)vec[V_Q], out);
     }
 
     // Ap = A p for an LhsDef; dot partial lands in partials[0]
     int lhs_apply(const Geom& q, const LhsDef& d, const S* pin, const S* mask, S* Ap, const int* live) {
         if (d.kind == 1) {
+            // one launch = two SpMM applications (Ldr, Ldr^T): 2 x 8 B/element algorithmic
+            if (cldr_fits(q))
+                return rows_cldr<EpiLhs>(q, pin, live, 0, 4, (const S*)nullptr, mask, Ap, d.hth, p.t_in, (S)d.c1, (S)d.c2);
             MG_TRY(rows<EpiStore>(q, g->op_ldr(), pin, live, 0, 2, vec[V_Q]));
             return rows<EpiLhs>(q, g->op_ldrt(), vec[V_Q], live, 0, 3, pin, mask, Ap, d.hth, p.t_in, (S)d.c1, (S)d.c2);
         }
@@ -580,6 +740,7 @@ struct Engine : EngineBase {
         c.beta_hist = record ? d_beta_hist : nullptr;
         c.nonfinite = d_nonfinite;
         const int K = p.max_cg_iter;
+        const int batch_max = p.cg_convergence == MGADMM_CG_BATCH_MAX ? 1 : 0;
         MG_HIP(hipMemsetAsync(d_nact, 0, sizeof(int) * K, st));
         if (record) {
             MG_TRY(fill(d_alpha_hist, (size_t)K * q.Bp, (S)NAN));
@@ -587,7 +748,9 @@ struct Engine : EngineBase {
         }
         S *r = vec[V_R], *pp = vec[V_P], *Ap = vec[V_AP];
         // r = rhs - A x0 ; p = r ; x = x0
-        if (d.kind == 1) {
+        if (d.kind == 1 && cldr_fits(q)) {
+            MG_TRY(rows_cldr<EpiCgInit>(q, x0, nullptr, 2, 7, (const S*)nullptr, rhs, mask, r, pp, xout, d.hth, p.t_in, (S)d.c1, (S)d.c2));
+        } else if (d.kind == 1) {
             MG_TRY(rows<EpiStore>(q, g->op_ldr(), x0, nullptr, 2, 2, vec[V_Q]));
             MG_TRY(rows<EpiCgInit>(q, g->op_ldrt(), vec[V_Q], nullptr, 2, 6, x0, rhs, mask, r, pp, xout, d.hth, p.t_in,
                                    (S)d.c1, (S)d.c2));
@@ -612,7 +775,7 @@ struct Engine : EngineBase {
             MG_TRY(lhs_apply(q, d, pp, nullptr, Ap, live));                  // Ap = A p (no mask: quirk Q2)
             MG_TRY((reduce<1>(q, FinCgAlpha<S>{c, k, q.Bp}, live)));
             MG_TRY(rows<EpiCgUpdate>(q, op_none(), Ap, live, 1, 3, (const S*)d_alpha, r));                 // r -= alpha Ap, r.r
-            MG_TRY((reduce<1>(q, FinCgBeta<S>{c, k, q.Bp, p.cg_tol}, live)));
+            MG_TRY((reduce<1>(q, FinCgBeta<S>{c, k, q.Bp, p.cg_tol, batch_max}, live)));
             MG_TRY(rows<EpiPUpdate>(q, op_none(), r, live, 1, 5, (const S*)d_alpha, (const S*)d_beta, xout, pp));   // x += alpha p, p = r + beta p
             prof_cur_ref = -1;
             MG_HIP(hipMemcpyAsync(h_nact + base + k, d_nact + k, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -623,6 +786,10 @@ struct Engine : EngineBase {
             }
         }
         if (!nact_locked) nact_cur += std::min(k, K);
+        if (batch_max) {          // one iteration count for the whole batch: the first iteration after which no sample was above the tolerance
+            hipLaunchKernelGGL(k_cg_batchmax_iters, dim3((q.B + 255) / 256), dim3(256), 0, st, (const int*)d_nact, std::min(k, K), iters_dev, q.B);
+            MG_HIP(hipGetLastError());
+        }
         if (n_iter_launched) *n_iter_launched = k;
         return MGADMM_OK;
     }
@@ -640,6 +807,7 @@ struct Engine : EngineBase {
             case MGADMM_OP_LDR: MG_TRY(op_store(q, g->op_ldr(), vec[V_IO0], vec[V_IO1])); break;
             case MGADMM_OP_LDRT: MG_TRY(op_store(q, g->op_ldrt(), vec[V_IO0], vec[V_IO1])); break;
             case MGADMM_OP_CLDR: MG_TRY(cldr(q, vec[V_IO0], vec[V_IO1])); break;
+            case MGADMM_OP_LN: MG_TRY(op_ln(q, vec[V_IO0], vec[V_IO1])); break;
             default: mg_set_error("apply: bad op %d", op); return MGADMM_ERR_INVALID;
         }
         return unpack(q, vec[V_IO1], y);
@@ -763,16 +931,27 @@ struct Engine : EngineBase {
     }
 
     // ---------------------------------------------------------------- combined_loop (ADMM.py:511-648)
-    int solve(const void* y, const void* mask, int mask_f32, int B, void* x_out, const mgadmm_state* state_out,
-              mgadmm_history* hist, hipStream_t s) override {
+    // every state tensor the ablation uses must be present in a warm-start state
+    int check_state_in(const void* x0, const mgadmm_state* si) const {
+        const int abl = p.ablation;
+        const bool has_phi = (abl == MGADMM_ABL_NONE || abl == MGADMM_ABL_DGLR), has_zd = (abl != MGADMM_ABL_DGLR);
+        MG_REQUIRE(x0 && si && si->zu && si->gamma_u, "solve_from: x0, state_in.zu and state_in.gamma_u are required");
+        MG_REQUIRE(!has_phi || (si->phi && si->gamma), "solve_from: state_in.phi and state_in.gamma are required for this ablation");
+        MG_REQUIRE(!has_zd || (si->zd && si->gamma_d), "solve_from: state_in.zd and state_in.gamma_d are required for this ablation");
+        return MGADMM_OK;
+    }
+
+    int solve(const void* y, const void* mask, int mask_f32, int B, const void* x0, const mgadmm_state* state_in, void* x_out,
+              const mgadmm_state* state_out, mgadmm_history* hist, hipStream_t s) override {
         MG_TRY(check_B(B, "solve"));
         MG_REQUIRE(y && x_out, "solve: null pointer");
+        if (state_in) MG_TRY(check_state_in(x0, state_in));
         st = s;
         if (p.path == MGADMM_PATH_LDS && !lds.ok) {
             mg_set_error("solve: the LDS-resident path needs float32, T*N*8 B + CSR <= 160 KiB and N*G <= 1024 (N=%d, T=%d)", N, T);
             return MGADMM_ERR_UNSUPPORTED;
         }
-        if (use_lds()) return solve_lds(y, mask, B, x_out, state_out, hist);
+        if (use_lds()) return solve_lds(y, mask, B, x0, state_in, x_out, state_out, hist);
         const Geom q = make_geom(B);
         MG_TRY(ensure_partials(q));
         const size_t ne = velems(q);
@@ -801,19 +980,33 @@ struct Engine : EngineBase {
             MG_TRY(pack(q, y, T, vec[V_Y]));
             MG_TRY(pack(q, mask, T, vec[V_MASK]));
             m = vec[V_MASK];
-            MG_TRY(interp_internal(q, vec[V_Y], m, mask_f32, vec[xc]));
+            if (!state_in) MG_TRY(interp_internal(q, vec[V_Y], m, mask_f32, vec[xc]));
         } else {
             MG_TRY(pack(q, y, p.t_in, vec[V_Y]));
-            MG_TRY(guess_internal(q, vec[V_Y], vec[xc]));
+            if (!state_in) MG_TRY(guess_internal(q, vec[V_Y], vec[xc]));
         }
-        MG_TRY(fill(vec[V_GU], ne, (S)0.1));
-        MG_TRY(fill(vec[V_GD], ne, (S)0.1));
-        if (has_phi) {
-            MG_TRY(fill(vec[V_GAM], ne, (S)0.1));
-            MG_TRY(op_store(q, g->op_ldr(), vec[xc], vec[phc]));
+        if (state_in) {                       // warm start: the saved state replaces ADMM.py:529-544
+            MG_TRY(pack(q, x0, T, vec[xc]));
+            MG_TRY(pack(q, state_in->zu, T, vec[zuc]));
+            MG_TRY(pack(q, state_in->gamma_u, T, vec[V_GU]));
+            if (has_zd) {
+                MG_TRY(pack(q, state_in->zd, T, vec[zdc]));
+                MG_TRY(pack(q, state_in->gamma_d, T, vec[V_GD]));
+            }
+            if (has_phi) {
+                MG_TRY(pack(q, state_in->phi, T, vec[phc]));
+                MG_TRY(pack(q, state_in->gamma, T, vec[V_GAM]));
+            }
+        } else {
+            MG_TRY(fill(vec[V_GU], ne, (S)0.1));
+            MG_TRY(fill(vec[V_GD], ne, (S)0.1));
+            if (has_phi) {
+                MG_TRY(fill(vec[V_GAM], ne, (S)0.1));
+                MG_TRY(op_store(q, g->op_ldr(), vec[xc], vec[phc]));
+            }
+            MG_HIP(hipMemcpyAsync(vec[zuc], vec[xc], ne * sizeof(S), hipMemcpyDeviceToDevice, st));
+            MG_HIP(hipMemcpyAsync(vec[zdc], vec[xc], ne * sizeof(S), hipMemcpyDeviceToDevice, st));
         }
-        MG_HIP(hipMemcpyAsync(vec[zuc], vec[xc], ne * sizeof(S), hipMemcpyDeviceToDevice, st));
-        MG_HIP(hipMemcpyAsync(vec[zdc], vec[xc], ne * sizeof(S), hipMemcpyDeviceToDevice, st));
 
         const S rho = (S)p.rho, rho_u = (S)p.rho_u, rho_d = (S)p.rho_d;
         int n_done = 0;
@@ -906,6 +1099,124 @@ struct Engine : EngineBase {
         return finish_history(hist, n_done, B, q.Bp, rc_final);
     }
 
+    // ---------------------------------------------------------------- two_loops (ADMM.py:410-508)
+    // Same kernels as `solve`, other schedule: the phi / gamma update moves to an outer loop and every outer iteration
+    // restarts the inner ADMM on (x, zu, zd, gamma_u, gamma_d) from zu = zd = x, gamma_u = gamma_d = 0.1.  No residual
+    // history (the reference records none there: "TODO: residual", ADMM.py:494, 506); CG counts per inner iteration.
+    int two_loops(const void* y, const void* mask, int mask_f32, int B, void* x_out, const mgadmm_state* state_out,
+                  mgadmm_history* hist, hipStream_t s) override {
+        MG_TRY(check_B(B, "two_loops"));
+        MG_REQUIRE(y && x_out, "two_loops: null pointer");
+        MG_REQUIRE(p.max_inner_iter >= 1, "two_loops: max_inner_iter must be >= 1 (got %d)", p.max_inner_iter);
+        st = s;
+        const Geom q = make_geom(B);
+        MG_TRY(ensure_partials(q));
+        const size_t ne = velems(q);
+        const int abl = p.ablation;
+        const bool has_phi = (abl == MGADMM_ABL_NONE || abl == MGADMM_ABL_DGLR);
+        const bool has_zd = (abl != MGADMM_ABL_DGLR);
+        const int n_outer = p.max_admm_iter, n_inner = p.max_inner_iter;
+        const size_t rows_needed = (size_t)n_outer * n_inner;
+        if (rows_needed > (size_t)max_admm_alloc) {          // d_cg_iters holds one row of 3 x Bp counts per inner iteration
+            if (d_cg_iters) MG_HIP(hipFree(d_cg_iters));
+            d_cg_iters = nullptr;
+            MG_HIP(hipMalloc(&d_cg_iters, sizeof(int) * rows_needed * 3 * Bp_max));
+            // d_hist / d_dxps keep their size: they are indexed by ADMM iteration < p.max_admm_iter <= rows_needed
+            double *nh = nullptr, *nd = nullptr;
+            MG_HIP(hipMalloc(&nh, sizeof(double) * rows_needed * MGADMM_NMETRIC));
+            MG_HIP(hipMalloc(&nd, sizeof(double) * rows_needed * T));
+            if (d_hist) (void)hipFree(d_hist);
+            if (d_dxps) (void)hipFree(d_dxps);
+            d_hist = nh; d_dxps = nd;
+            max_admm_alloc = (int)rows_needed;
+        }
+        MG_HIP(hipMemsetAsync(d_nonfinite, 0, sizeof(int), st));
+        MG_HIP(hipMemsetAsync(d_ps, 0, sizeof(double) * MGADMM_NMETRIC * q.Bp, st));
+        MG_HIP(hipMemsetAsync(d_cg_iters, 0, sizeof(int) * rows_needed * 3 * q.Bp, st));
+        int xc = V_XA, xn = V_XB, zuc = V_ZUA, zun = V_ZUB, zdc = V_ZDA, zdn = V_ZDB, phc = V_PHIA, phn = V_PHIB;
+        const S* m = nullptr;
+        if (mask) {
+            MG_TRY(pack(q, y, T, vec[V_Y]));
+            MG_TRY(pack(q, mask, T, vec[V_MASK]));
+            m = vec[V_MASK];
+            MG_TRY(interp_internal(q, vec[V_Y], m, mask_f32, vec[xc]));
+        } else {
+            MG_TRY(pack(q, y, p.t_in, vec[V_Y]));
+            MG_TRY(guess_internal(q, vec[V_Y], vec[xc]));
+        }
+        if (has_phi) {
+            MG_TRY(fill(vec[V_GAM], ne, (S)0.1));
+            MG_TRY(op_store(q, g->op_ldr(), vec[xc], vec[phc]));
+        }
+        const S rho = (S)p.rho, rho_u = (S)p.rho_u, rho_d = (S)p.rho_d;
+        int n_done = 0;
+        for (int o = 0; o < n_outer; ++o) {
+            MG_TRY(fill(vec[V_GU], ne, (S)0.1));
+            MG_TRY(fill(vec[V_GD], ne, (S)0.1));
+            MG_HIP(hipMemcpyAsync(vec[zuc], vec[xc], ne * sizeof(S), hipMemcpyDeviceToDevice, st));
+            MG_HIP(hipMemcpyAsync(vec[zdc], vec[xc], ne * sizeof(S), hipMemcpyDeviceToDevice, st));
+            for (int in = 0; in < n_inner; ++in) {
+                if (has_phi) {
+                    MG_TRY(rows<EpiLin2>(q, op_none(), vec[V_GAM], nullptr, 3, 3, (const S*)vec[phc], vec[V_TMP], (S)1, rho));
+                    MG_TRY(rows<EpiRhsX>(q, g->op_ldrt(), vec[V_TMP], nullptr, 2, has_zd ? 7 : 5, (const S*)vec[zuc],
+                                         (const S*)vec[zdc], (const S*)vec[V_GU], (const S*)vec[V_GD], (const S*)vec[V_Y],
+                                         vec[V_RHS], rho_u, rho_d, 1, has_zd ? 1 : 0));
+                } else {
+                    MG_TRY(rows<EpiRhsX>(q, op_none(), vec[zuc], nullptr, 3, 6, (const S*)vec[zuc], (const S*)vec[zdc],
+                                         (const S*)vec[V_GU], (const S*)vec[V_GD], (const S*)vec[V_Y], vec[V_RHS], rho_u,
+                                         rho_d, 0, 1));
+                }
+                int* it_base = d_cg_iters + ((size_t)o * n_inner + in) * 3 * q.Bp;
+                MG_TRY(cg_internal(q, lhs_def(MGADMM_LHS_X), vec[V_RHS], vec[xc], m, vec[xn], it_base, false));
+                MG_TRY(rows<EpiLin2>(q, op_none(), vec[V_GU], nullptr, 3, 3, (const S*)vec[xn], vec[V_RHS], (S)0.5, (S)(p.rho_u / 2)));
+                MG_TRY(cg_internal(q, lhs_def(MGADMM_LHS_ZU), vec[V_RHS], vec[zuc], nullptr, vec[zun], it_base + q.Bp, false));
+                if (has_zd) {
+                    MG_TRY(rows<EpiLin2>(q, op_none(), vec[V_GD], nullptr, 3, 3, (const S*)vec[xn], vec[V_RHS], (S)0.5, (S)(p.rho_d / 2)));
+                    MG_TRY(cg_internal(q, lhs_def(MGADMM_LHS_ZD), vec[V_RHS], vec[zdc], nullptr, vec[zdn], it_base + 2 * q.Bp, false));
+                }
+                const S* zd_now = has_zd ? vec[zdn] : vec[zdc];
+                // gamma_u += rho_u (x - zu), gamma_d += rho_d (x - zd)   (ADMM.py:488-490); the fused norms are not kept
+                MG_TRY(rows<EpiDual>(q, op_none(), vec[xn], nullptr, 3, has_zd ? 11 : 6, (const S*)vec[xc], (const S*)vec[zun],
+                                     (const S*)vec[zuc], zd_now, (const S*)vec[zdc], (const S*)vec[V_Y], m, vec[V_GU],
+                                     vec[V_GD], rho_u, rho_d, has_zd ? 1 : 0, p.t_in));
+                std::swap(xc, xn);
+                std::swap(zuc, zun);
+                if (has_zd) std::swap(zdc, zdn);
+            }
+            if (has_phi) {          // phi = phi_direct(x, gamma); gamma += rho (phi - Ldr x)   (ADMM.py:497-504)
+                MG_TRY(rows<EpiPhi>(q, g->op_ldr(), vec[xc], nullptr, 2, 5, (const S*)vec[phc], vec[phn], vec[V_GAM], rho,
+                                    (S)(p.mu_d1 / p.rho), 1));
+                std::swap(phc, phn);
+            }
+            n_done = o + 1;
+        }
+        MG_TRY(unpack(q, vec[xc], x_out));
+        if (state_out) {
+            if (state_out->zu) MG_TRY(unpack(q, vec[zuc], state_out->zu));
+            if (state_out->zd) MG_TRY(unpack(q, vec[zdc], state_out->zd));
+            if (state_out->phi && has_phi) MG_TRY(unpack(q, vec[phc], state_out->phi));
+            if (state_out->gamma && has_phi) MG_TRY(unpack(q, vec[V_GAM], state_out->gamma));
+            if (state_out->gamma_u) MG_TRY(unpack(q, vec[V_GU], state_out->gamma_u));
+            if (state_out->gamma_d) MG_TRY(unpack(q, vec[V_GD], state_out->gamma_d));
+        }
+        if (hist) {
+            hist->n_iters = n_done;
+            if (hist->cg_iters) {
+                std::vector<int> tmp(rows_needed * 3 * q.Bp);
+                MG_HIP(hipMemcpyAsync(tmp.data(), d_cg_iters, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost, st));
+                MG_HIP(hipStreamSynchronize(st));
+                for (size_t r = 0; r < rows_needed * 3; ++r) memcpy(hist->cg_iters + r * B, tmp.data() + r * q.Bp, sizeof(int) * B);
+            }
+        }
+        MG_HIP(hipMemcpyAsync(h_flag, d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
+        MG_HIP(hipStreamSynchronize(st));
+        if (h_flag[0]) {
+            mg_set_error("two_loops: NaN/Inf met in the iterates (cf. the asserts of ADMM.py:432-504)");
+            return MGADMM_ERR_NONFINITE;
+        }
+        return MGADMM_OK;
+    }
+
     // ---------------------------------------------------------------- LDS-resident fused path
     int plan_lds() {
         lds = LdsPlan();
@@ -937,7 +1248,8 @@ struct Engine : EngineBase {
         // fall back to the unpadded stride when the padded vectors do not fit
         int ts = (T + 3) / 4 * 4;
         if (((ts / 4) & 1) == 0) ts += 4;
-        auto bytes_for = [&](int stride) { return (size_t)8 * N * stride + 16 + 32 * sizeof(float) +  (size_t)4 * off; };   // P, Q + reduction slots + CSR image
+        const int sb = getenv("MGADMM_LDS_SB") ? atoi(getenv("MGADMM_LDS_SB")) : 0;   // 1: one LDS vector for p and q (experiments)
+        auto bytes_for = [&](int stride) { return (size_t)(sb ? 4 : 8) * N * stride + 16 + 32 * sizeof(float) +  (size_t)4 * off; };   // P, Q + reduction slots + CSR image
         if (bytes_for(ts) > 160 * 1024) ts = T;
         lds.TS = ts;
         lds.lds_bytes = bytes_for(ts);
@@ -946,6 +1258,10 @@ struct Engine : EngineBase {
         lds.G = T / best;
         lds.nthreads = N * lds.G;
         lds.block = (lds.nthreads + 63) / 64 * 64;
+        lds.sb = sb ? 1 : 0;
+        // register budget: the kernel is compiled for the smallest workgroup-size class that holds the block
+        lds.maxt = (best == 12 && lds.block <= 640) ? 640 : 1024;
+        if (lds.sb && !((best == 12 && lds.maxt == 640) || best == 8)) lds.sb = 0;
         std::vector<int> img(off, 0);
         auto put_csr = [&](const HostCsr& h, int off_rp, int off_en) {
             for (int i = 0; i <= N; ++i) img[off_rp + i] = h.rowptr[i];
@@ -966,22 +1282,16 @@ struct Engine : EngineBase {
         return MGADMM_OK;
     }
 
-    template <int TPG>
     int launch_lds(const LdsArgs& a, int B) {
-        return a.band ? launch_lds2<TPG, true>(a, B) : launch_lds2<TPG, false>(a, B);
-    }
-    template <int TPG, bool BAND>
-    int launch_lds2(const LdsArgs& a, int B) {
-        auto fn = k_admm_lds<TPG, BAND>;
-        MG_TRY(allow_dynamic_lds((const void*)fn, 160 * 1024));
         const bool timed = prof_open(0, 0.0);
-        hipLaunchKernelGGL(fn, dim3(B), dim3(lds.block), lds.lds_bytes, st, a);
+        LdsLaunch L{lds.TPG, lds.maxt, lds.sb, lds.block, lds.lds_bytes};
+        const int rc = mg_lds_iteration(L, a, B, st);
         if (timed) prof_close();
-        MG_HIP(hipGetLastError());
-        return MGADMM_OK;
+        return rc;
     }
 
-    int solve_lds(const void* y, const void* mask, int B, void* x_out, const mgadmm_state* state_out, mgadmm_history* hist) {
+    int solve_lds(const void* y, const void* mask, int B, const void* x0, const mgadmm_state* state_in, void* x_out,
+                  const mgadmm_state* state_out, mgadmm_history* hist) {
         if constexpr (!std::is_same<S, float>::value) {
             return MGADMM_ERR_UNSUPPORTED;
         } else {
@@ -1006,20 +1316,22 @@ struct Engine : EngineBase {
             MG_HIP(hipMemsetAsync(d_cg_iters, 0, sizeof(int) * (size_t)max_it * 3 * Bp, st));
             float *xa = vec[V_XA], *xb = vec[V_XB];
             float *zu = vec[V_ZUA], *zd = vec[V_ZDA], *phi = vec[V_PHIA], *gam = vec[V_GAM], *gu = vec[V_GU], *gd = vec[V_GD];
-            {
+            if (state_in) {                   // warm start: the state tensors are already in this path's (B, T*N) layout
+                const size_t nb = (size_t)B * TN * sizeof(float);
+                auto cp = [&](float* dst, const void* src) { return hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, st); };
+                MG_HIP(cp(xa, x0));
+                MG_HIP(cp(zu, state_in->zu));
+                MG_HIP(cp(gu, state_in->gamma_u));
+                if (has_zd) { MG_HIP(cp(zd, state_in->zd)); MG_HIP(cp(gd, state_in->gamma_d)); }
+                if (has_phi) { MG_HIP(cp(phi, state_in->phi)); MG_HIP(cp(gam, state_in->gamma)); }
+            } else {
                 float tm = 0, t2m = 0;
                 for (int t = 0; t < p.t_in; ++t) { tm += (float)t; t2m += (float)t * (float)t; }
                 tm /= (float)p.t_in;
                 t2m /= (float)p.t_in;
                 const float den = t2m - tm * tm;
-                dim3 grid((N + 255) / 256, B);
-                if (mask)
-                    hipLaunchKernelGGL((k_init_lds<true>), grid, dim3(256), 0, st, T, p.t_in, N, B, tm, den, (const float*)y,
-                                       (const float*)mask, xa, zu, zd, gam, gu, gd, d_nonfinite);
-                else
-                    hipLaunchKernelGGL((k_init_lds<false>), grid, dim3(256), 0, st, T, p.t_in, N, B, tm, den, (const float*)y,
-                                       (const float*)nullptr, xa, zu, zd, gam, gu, gd, d_nonfinite);
-                MG_HIP(hipGetLastError());
+                MG_TRY(mg_lds_init(mask != nullptr, T, p.t_in, N, B, tm, den, (const float*)y, (const float*)mask, xa, zu, zd, gam, gu, gd,
+                                   d_nonfinite, st));
             }
             LdsArgs a{};
             a.T = T; a.N = N; a.TN = (int)TN; a.TS = lds.TS; a.t_in = p.t_in; a.G = lds.G; a.B = B; a.Bp = Bp;
@@ -1046,29 +1358,15 @@ struct Engine : EngineBase {
             int n_done = 0, rc_final = MGADMM_OK;
             float *xc = xa, *xn = xb;
             for (int it = 0; it < max_it; ++it) {
-                a.first = it == 0;
+                a.first = it == 0 && !state_in;      // phi = Ldr x0 is formed by the first launch of a cold start
                 a.x_old = xc; a.x_new = xn;
                 a.cg_iters = d_cg_iters + (size_t)it * 3 * Bp;
                 if (record) {
                     MG_TRY(fill((S*)d_alpha_hist, 3 * K * Bp, (S)NAN));
                     MG_TRY(fill((S*)d_beta_hist, 3 * K * Bp, (S)NAN));
                 }
-                switch (lds.TPG) {
-                    case 1: MG_TRY(launch_lds<1>(a, B)); break;
-                    case 2: MG_TRY(launch_lds<2>(a, B)); break;
-                    case 3: MG_TRY(launch_lds<3>(a, B)); break;
-                    case 4: MG_TRY(launch_lds<4>(a, B)); break;
-                    case 6: MG_TRY(launch_lds<6>(a, B)); break;
-                    case 8: MG_TRY(launch_lds<8>(a, B)); break;
-                    case 12: MG_TRY(launch_lds<12>(a, B)); break;
-                    default: mg_set_error("solve_lds: bad TPG"); return MGADMM_ERR_UNSUPPORTED;
-                }
-                const int nsl = (B + 63) / 64;
-                hipLaunchKernelGGL(k_dxps_sm, dim3(((int)TN + 255) / 256, nsl), dim3(256), 0, st, (int)TN, B, (const float*)xn,
-                                   (const float*)xc, d_m2 + TN);
-                hipLaunchKernelGGL(k_dxps_sm_mean, dim3(((int)TN + 255) / 256), dim3(256), 0, st, (int)TN, B, nsl,
-                                   (const double*)(d_m2 + TN), d_m2);
-                hipLaunchKernelGGL(k_dxps_sm_final, dim3(T), dim3(256), 0, st, T, N, (const double*)d_m2, d_dxps + (size_t)it * T);
+                MG_TRY(launch_lds(a, B));
+                MG_TRY(mg_lds_dxps(T, N, B, (const float*)xn, (const float*)xc, d_m2, d_dxps + (size_t)it * T, st));
                 hipLaunchKernelGGL(k_batch_metrics, dim3(MGADMM_NMETRIC), dim3(256), 0, st, (const double*)d_ps, Bp, B,
                                    d_hist + (size_t)it * MGADMM_NMETRIC,
                                    (hist && hist->metrics_per_sample) ? d_hist_ps + (size_t)it * MGADMM_NMETRIC * B : nullptr);
@@ -1152,93 +1450,3 @@ struct Engine : EngineBase {
 };
 
 }  // namespace
-
-EngineBase* mg_make_engine_f32(mgadmm_solver* s) { return new Engine<float>(s); }
-EngineBase* mg_make_engine_f64(mgadmm_solver* s) { return new Engine<double>(s); }
-
-// ------------------------------------------------------------------------------------ C ABI
-extern "C" {
-
-int mgadmm_solver_create(mgadmm_graph* g, const mgadmm_params* p, int32_t max_batch, mgadmm_solver** out) {
-    MG_REQUIRE(g && p && out, "solver_create: null argument");
-    MG_REQUIRE(max_batch >= 1, "solver_create: max_batch must be >= 1");
-    MG_REQUIRE(p->dtype == MGADMM_F32 || p->dtype == MGADMM_F64, "solver_create: bad dtype %d", p->dtype);
-    MG_REQUIRE(p->t_in >= 1 && p->t_in <= g->T, "solver_create: t_in %d outside [1, T=%d]", p->t_in, g->T);
-    MG_REQUIRE(p->ablation >= 0 && p->ablation <= 3, "solver_create: ablation should be one of None, DGTV, DGLR, UT");
-    MG_REQUIRE(p->max_cg_iter >= 1 && p->max_admm_iter >= 1, "solver_create: iteration limits must be >= 1");
-    mgadmm_solver* s = new mgadmm_solver();
-    s->g = g;
-    s->p = *p;
-    s->Bmax = max_batch;
-    s->eng = p->dtype == MGADMM_F32 ? mg_make_engine_f32(s) : mg_make_engine_f64(s);
-    int rc = s->eng->init();
-    if (rc != MGADMM_OK) {
-        delete s->eng;
-        delete s;
-        return rc;
-    }
-    *out = s;
-    return MGADMM_OK;
-}
-
-int mgadmm_solver_destroy(mgadmm_solver* s) {
-    if (!s) return MGADMM_OK;
-    delete s->eng;
-    delete s;
-    return MGADMM_OK;
-}
-
-int mgadmm_solver_set_params(mgadmm_solver* s, const mgadmm_params* p) {
-    MG_REQUIRE(s && p, "set_params: null argument");
-    return s->eng->set_params(*p);
-}
-
-int64_t mgadmm_solver_workspace_bytes(const mgadmm_solver* s) { return s ? s->eng->workspace_bytes() : 0; }
-int mgadmm_solver_path(const mgadmm_solver* s, int32_t B) { return s ? s->eng->path_for(B) : MGADMM_ERR_INVALID; }
-
-int mgadmm_solver_query(const mgadmm_solver* s, int32_t what, int64_t* out) {
-    MG_REQUIRE(s && out, "solver_query: null argument");
-    return s->eng->query(what, out);
-}
-
-int mgadmm_apply(mgadmm_solver* s, int32_t op, const void* x, void* y, int32_t B, void* stream) {
-    MG_REQUIRE(s, "apply: null solver");
-    return s->eng->apply(op, x, y, B, (hipStream_t)stream);
-}
-int mgadmm_lhs(mgadmm_solver* s, int32_t which, const void* x, const void* mask, void* y, int32_t B, void* stream) {
-    MG_REQUIRE(s, "lhs: null solver");
-    return s->eng->lhs(which, x, mask, y, B, (hipStream_t)stream);
-}
-int mgadmm_phi_direct(mgadmm_solver* s, const void* x, const void* gamma, void* phi, int32_t B, void* stream) {
-    MG_REQUIRE(s, "phi_direct: null solver");
-    return s->eng->phi_direct(x, gamma, phi, B, (hipStream_t)stream);
-}
-int mgadmm_initial_guess(mgadmm_solver* s, const void* y, void* x, int32_t B, void* stream) {
-    MG_REQUIRE(s, "initial_guess: null solver");
-    return s->eng->initial_guess(y, x, B, (hipStream_t)stream);
-}
-int mgadmm_initial_interpolation(mgadmm_solver* s, const void* y, const void* mask, int32_t mask_is_f32, void* x,
-                                 int32_t B, void* stream) {
-    MG_REQUIRE(s, "initial_interpolation: null solver");
-    return s->eng->initial_interpolation(y, mask, mask_is_f32, x, B, (hipStream_t)stream);
-}
-int mgadmm_cg(mgadmm_solver* s, int32_t which, const void* rhs, const void* x0, const void* mask, void* x, int32_t* iters,
-              double* alpha, double* beta, int32_t B, void* stream) {
-    MG_REQUIRE(s, "cg: null solver");
-    return s->eng->cg(which, rhs, x0, mask, x, iters, alpha, beta, B, (hipStream_t)stream);
-}
-int mgadmm_solve(mgadmm_solver* s, const void* y, const void* mask, int32_t mask_is_f32, int32_t B, void* x_out,
-                 const mgadmm_state* state_out, mgadmm_history* hist, void* stream) {
-    MG_REQUIRE(s, "solve: null solver");
-    return s->eng->solve(y, mask, mask_is_f32, B, x_out, state_out, hist, (hipStream_t)stream);
-}
-int mgadmm_prof_begin(mgadmm_solver* s) {
-    MG_REQUIRE(s, "prof_begin: null solver");
-    return s->eng->prof_begin();
-}
-int mgadmm_prof_end(mgadmm_solver* s, int64_t* counts, double* total_ms, double* bytes) {
-    MG_REQUIRE(s && counts && total_ms && bytes, "prof_end: null argument");
-    return s->eng->prof_end(counts, total_ms, bytes);
-}
-
-}  // extern "C"

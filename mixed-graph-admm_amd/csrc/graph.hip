@@ -116,7 +116,7 @@ int mg_rcm_order(const HostCsr& A, const HostCsr* B, std::vector<int>& perm) {
 // next cluster is seeded on the boundary of the previous ones.  Consecutive rows of the resulting order are
 // graph neighbours far more often than under RCM (kNN graph, N=10k: 90 % of the edges within +-16 rows vs
 // 38 %), which is what the LDS-tiled row kernel needs.
-int mg_cluster_order(const HostCsr& A, const HostCsr* B, int csize, std::vector<int>& perm) {
+int mg_cluster_order(const HostCsr& A, const HostCsr* B, int csize, std::vector<int>& perm, std::vector<int>* starts) {
     const int n = A.n;
     std::vector<std::vector<int>> adj(n);
     auto add = [&](const HostCsr& M) {
@@ -158,6 +158,7 @@ int mg_cluster_order(const HostCsr& A, const HostCsr* B, int csize, std::vector<
         }
         std::priority_queue<PI> heap;
         std::vector<int> touched;
+        if (starts) starts->push_back((int)perm.size());      // first internal row of this cluster
         heap.push(PI(0, -seed));
         int size = 0;
         while (!heap.empty() && size < csize) {
@@ -317,7 +318,8 @@ extern "C" int mgadmm_graph_create(const mgadmm_graph_desc* d, mgadmm_graph** ou
         mg_rcm_order(g->hWu, g->mode == MGADMM_TEMPORAL_SPATIAL ? &g->hWd : nullptr, g->perm);
         g->has_perm = true;
     } else if (d->reorder >= 2) {
-        mg_cluster_order(g->hWu, g->mode == MGADMM_TEMPORAL_SPATIAL ? &g->hWd : nullptr, 32, g->perm);
+        // clusters of 64 rows: one cluster = one tile of the fused cLdr kernel (8 tiles of the 8-row SpMM kernel)
+        mg_cluster_order(g->hWu, g->mode == MGADMM_TEMPORAL_SPATIAL ? &g->hWd : nullptr, 64, g->perm, &g->cluster_starts);
         g->has_perm = true;
     }
     g->reorder = d->reorder;
@@ -361,6 +363,7 @@ extern "C" int mgadmm_graph_destroy(mgadmm_graph* g) {
     free_csr(g->Wu); free_csr(g->Wd); free_csr(g->WdT);
     if (g->band_w) (void)hipFree(g->band_w);
     if (g->d_perm) (void)hipFree(g->d_perm);
+    if (g->ln_rowsum) (void)hipFree(g->ln_rowsum);
     delete g;
     return MGADMM_OK;
 }

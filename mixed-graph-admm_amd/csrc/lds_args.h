@@ -1,0 +1,49 @@
+// Launch interface of the LDS-resident fused path (kernels in lds_kernels.h, compiled in lds_launch.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct LdsArgs {
+    int T, N, TN, TS, t_in, G, B, Bp;   // TS: LDS row stride (floats) of a node's time row, >= T
+    int nthreads;          // N * G active threads
+    int has_phi, has_zd, first;
+    int lhsx_kind;         // 1: LHS_x contains cLdr, 0: diagonal ('DGTV'/'UT')
+    int band, skip, q1;
+    int max_cg;
+    int record;            // alpha/beta history
+    float rho, rho_u, rho_d, mu_u, mu_d1, mu_d2;
+    float cx1, cx2;        // LHS_x = HtH + cx1*I + cx2*cLdr
+    double cg_tol;
+    // CSR image (global): ints laid out as [rp_u N+1][rp_d N+1][rp_t N+1][ent_u 2*nnz_u][ent_d ..][ent_t ..]
+    const int* csr;
+    int csr_ints, off_rp_u, off_rp_d, off_rp_t, off_en_u, off_en_d, off_en_t;
+    const float* band_w;   // [T*skip] (band mode)
+    // state, sample-major (B, TN)
+    const float* x_old;
+    float* x_new;
+    float *zu, *zd, *phi, *gam, *gu, *gd;
+    const float* y;        // (B, t_in, N) prediction / (B, T, N) mask mode
+    const float* mask;     // (B, T, N) or nullptr
+    // outputs
+    double* ps;            // [NMETRIC][Bp] per-sample metric sums
+    int* cg_iters;         // [3][Bp]
+    float* alpha_hist;     // [3][max_cg][Bp] or nullptr
+    float* beta_hist;
+    int* nonfinite;
+};
+
+// Execution plan of k_admm_lds chosen by Engine::plan_lds
+struct LdsLaunch {
+    int tpg;        // time steps per thread
+    int maxt;       // workgroup-size class the kernel was compiled for (640 / 1024)
+    int sb;         // single LDS vector (two workgroups per CU with the 640-thread class)
+    int block;      // threads per workgroup
+    size_t lds_bytes;
+};
+
+// one ADMM iteration for B samples (one workgroup per sample); returns a mgadmm_status
+int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st);
+// initial state in sample-major layout (ADMM.py:528-544)
+int mg_lds_init(bool masked, int T, int t_in, int N, int B, float tm, float den, const float* y, const float* mask, float* x,
+                float* zu, float* zd, float* gam, float* gu, float* gd, int* nonfinite, hipStream_t st);
+// delta_x_per_step on the sample-major layout (ADMM.py:614): scratch = double[TN * (1 + ceil(B/64))], out = double[T]
+int mg_lds_dxps(int T, int N, int B, const float* x, const float* xo, double* scratch, double* out, hipStream_t st);

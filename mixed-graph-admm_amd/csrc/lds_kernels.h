@@ -16,35 +16,8 @@
 // T*N*4 B through HBM instead of ~650.
 #pragma once
 #include "common.h"
+#include "lds_args.h"
 
-struct LdsArgs {
-    int T, N, TN, TS, t_in, G, B, Bp;   // TS: LDS row stride (floats) of a node's time row, >= T
-    int nthreads;          // N * G active threads
-    int has_phi, has_zd, first;
-    int lhsx_kind;         // 1: LHS_x contains cLdr, 0: diagonal ('DGTV'/'UT')
-    int band, skip, q1;
-    int max_cg;
-    int record;            // alpha/beta history
-    float rho, rho_u, rho_d, mu_u, mu_d1, mu_d2;
-    float cx1, cx2;        // LHS_x = HtH + cx1*I + cx2*cLdr
-    double cg_tol;
-    // CSR image (global): ints laid out as [rp_u N+1][rp_d N+1][rp_t N+1][ent_u 2*nnz_u][ent_d ..][ent_t ..]
-    const int* csr;
-    int csr_ints, off_rp_u, off_rp_d, off_rp_t, off_en_u, off_en_d, off_en_t;
-    const float* band_w;   // [T*skip] (band mode)
-    // state, sample-major (B, TN)
-    const float* x_old;
-    float* x_new;
-    float *zu, *zd, *phi, *gam, *gu, *gd;
-    const float* y;        // (B, t_in, N) prediction / (B, T, N) mask mode
-    const float* mask;     // (B, T, N) or nullptr
-    // outputs
-    double* ps;            // [NMETRIC][Bp] per-sample metric sums
-    int* cg_iters;         // [3][Bp]
-    float* alpha_hist;     // [3][max_cg][Bp] or nullptr
-    float* beta_hist;
-    int* nonfinite;
-};
 
 // wave64 sum with DPP row shifts / row broadcasts (no LDS traffic); the total ends up in lane 63 and is
 // broadcast with readlane.  Fixed association order -> bitwise repeatable.
@@ -171,6 +144,10 @@ struct LdsCtx {
         const float* row = base + coloff;
         lds_load<TPG>(row, v);
         if (shift == 0) return;
+        if (TPG == T) {                      // the thread owns the whole time axis: the element beyond either end is 0
+            v[shift < 0 ? TPG - 1 : 0] = 0.f;
+            return;
+        }
         const bool lo_ok = t0 > 0, hi_ok = t0 + TPG < T;
         float edge;
         if constexpr (TPG % 4 == 0) {
@@ -298,7 +275,7 @@ struct LdsCtx {
 // dc = diagonal coefficient of the own elements (H^T H or mask value, plus the rho/2 terms), see lds_diag.
 // Returns sum_k v_k * (A v)_k of the own elements.  Uses ctx.Q as scratch; contains a barrier for KIND 1.
 // Callers separate successive calls by barriers.
-template <int TPG, bool BAND, int KIND>
+template <int TPG, bool BAND, int KIND, bool SB>
 __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND>& c, const float (&v)[TPG], float (&av)[TPG], const float (&dc)[TPG],
                                            float c2) {
     float l[TPG];
@@ -308,10 +285,9 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND>& c, const flo
         float q[TPG];
 #pragma unroll
         for (int k = 0; k < TPG; ++k) q[k] = 0.f;
-        if (c.active) {
-            c.op_ldr(c.P, v, q);
-            c.put(c.Q, q);
-        }
+        if (c.active) c.op_ldr(c.P, v, q);
+        if (SB) __syncthreads();           // single LDS vector (Q aliases P): every gather of p is done before q replaces it
+        c.put(c.Q, q);
         __syncthreads();
         if (c.active) c.op_ldrt(c.Q, q, l);
     } else if (KIND == 2) {
@@ -340,7 +316,7 @@ __device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND>& c, const float
 // p in registers with a copy in LDS (ctx.P) for the neighbours' gathers, A p in registers.  x holds x0 on entry and the solution on exit.  dmask: diagonal
 // of the initial residual when a mask is given (global memory); the iterations always use [t<t_in]
 // (quirk Q2).  Returns the iteration count (k+1) or -1.  Entry requirement: no thread still reads P/Q.
-template <int TPG, bool BAND, int KIND>
+template <int TPG, bool BAND, int KIND, bool SB>
 __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
                       int hth, int t_in, float c1, float c2, int max_cg, double tol, float* ah, float* bh, int Bp,
                       int* nonfinite) {
@@ -348,7 +324,7 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, 
     c.put(c.P, x);
     __syncthreads();
     lds_diag<TPG, BAND>(c, dmask, hth, t_in, c1, dc);
-    (void)lds_apply<TPG, BAND, KIND>(c, x, av, dc, c2);
+    (void)lds_apply<TPG, BAND, KIND, SB>(c, x, av, dc, c2);
     if (dmask != nullptr) lds_diag<TPG, BAND>(c, nullptr, hth, t_in, c1, dc);     // quirk Q2: iterations use [t < t_in]
     float part = 0.f;
 #pragma unroll
@@ -362,7 +338,7 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, 
     int iters = -1;
     for (int it = 0; it < max_cg; ++it) {
         __syncthreads();                 // p complete in LDS
-        part = lds_apply<TPG, BAND, KIND>(c, pv, av, dc, c2);
+        part = lds_apply<TPG, BAND, KIND, SB>(c, pv, av, dc, c2);
         const float pAp = br.sumf(part);         // barrier: every gather from P/Q of this iteration is done
         const float alpha = rr / pAp;
         part = 0.f;
@@ -394,12 +370,15 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, 
     return iters;
 }
 
-template <int TPG, bool BAND>
-__global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
+// MAXT: workgroup-size class the kernel is compiled for (register budget).  SB: single LDS vector (q = Ldr p replaces p
+// in place, one more barrier per cLdr application); with the 640-thread class it is compiled for TWO resident
+// workgroups per CU (5 waves per SIMD, <= 96 VGPRs): two samples in flight per CU overlap each other's barriers.
+template <int TPG, bool BAND, int MAXT, bool SB>
+__global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(LdsArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     float* P = reinterpret_cast<float*>(lds_raw);
     const int LN = a.N * a.TS;                                         // floats per LDS vector (TS % 4 == 0 or TS == T)
-    float* Q = P + LN;
+    float* Q = SB ? P : P + LN;                                      // SB: one LDS vector serves p and q = Ldr p in turn
     float* red = Q + LN + ((4 - (LN & 3)) & 3);                       // 16-byte aligned, 2 x 16 floats
     int* csr = reinterpret_cast<int*>(red + 32);
     const int tid = threadIdx.x;
@@ -493,8 +472,8 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
 
     // ---- x solve (ADMM.py:571)
     int itx;
-    if (a.lhsx_kind == 1) itx = lds_cg<TPG, BAND, 1>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, a.cx2, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
-    else itx = lds_cg<TPG, BAND, 0>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, 0.f, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
+    if (a.lhsx_kind == 1) itx = lds_cg<TPG, BAND, 1, SB>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, a.cx2, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
+    else itx = lds_cg<TPG, BAND, 0, SB>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, 0.f, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
     c.putg(xn, x);
 
     {
@@ -530,7 +509,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
                 rhs[k] = gu[c.gl(k)] / 2.f + a.rho_u / 2.f * xn[c.gl(k)];
             }
         }
-        itzu = lds_cg<TPG, BAND, 2>(c, br, z, rhs, nullptr, 0, 0, a.rho_u / 2.f, a.mu_u, a.max_cg, a.cg_tol, ah ? ah + hstride : nullptr,
+        itzu = lds_cg<TPG, BAND, 2, SB>(c, br, z, rhs, nullptr, 0, 0, a.rho_u / 2.f, a.mu_u, a.max_cg, a.cg_tol, ah ? ah + hstride : nullptr,
                               bh ? bh + hstride : nullptr, a.Bp, a.nonfinite);
         double m_prizu = 0, m_dualzu = 0;
         if (c.active) {
@@ -559,7 +538,7 @@ __global__ __launch_bounds__(1024) void k_admm_lds(LdsArgs a) {
                 rhs[k] = gd[c.gl(k)] / 2.f + a.rho_d / 2.f * xn[c.gl(k)];
             }
         }
-        itzd = lds_cg<TPG, BAND, 1>(c, br, z, rhs, nullptr, 0, 0, a.rho_d / 2.f, a.mu_d2, a.max_cg, a.cg_tol,
+        itzd = lds_cg<TPG, BAND, 1, SB>(c, br, z, rhs, nullptr, 0, 0, a.rho_d / 2.f, a.mu_d2, a.max_cg, a.cg_tol,
                               ah ? ah + 2 * hstride : nullptr, bh ? bh + 2 * hstride : nullptr, a.Bp, a.nonfinite);
         double m_prizd = 0, m_dualzd = 0;
         if (c.active) {

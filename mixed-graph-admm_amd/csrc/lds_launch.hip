@@ -1,0 +1,77 @@
+// LDS-resident fused ADMM path: kernel instantiations and launches (own translation unit: the library builds in parallel).
+#include <mutex>
+#include <utility>
+#include <vector>
+
+#include "lds_kernels.h"
+
+namespace {
+
+std::mutex g_attr_mu;
+std::vector<std::pair<const void*, int>> g_attr_done;     // (kernel, device) pairs whose dynamic-LDS limit has been raised
+
+int allow_lds(const void* fn, int bytes) {
+    int dev = 0;
+    MG_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    for (auto& e : g_attr_done)
+        if (e.first == fn && e.second == dev) return MGADMM_OK;
+    MG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));   // a per-DEVICE property
+    g_attr_done.push_back({fn, dev});
+    return MGADMM_OK;
+}
+
+template <int TPG, bool BAND, int MAXT, bool SB>
+int launch(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st) {
+    auto fn = k_admm_lds<TPG, BAND, MAXT, SB>;
+    MG_TRY(allow_lds((const void*)fn, 160 * 1024));
+    hipLaunchKernelGGL(fn, dim3(B), dim3(L.block), L.lds_bytes, st, a);
+    MG_HIP(hipGetLastError());
+    return MGADMM_OK;
+}
+
+template <int TPG, int MAXT, bool SB>
+int launch_b(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st) {
+    return a.band ? launch<TPG, true, MAXT, SB>(L, a, B, st) : launch<TPG, false, MAXT, SB>(L, a, B, st);
+}
+
+}  // namespace
+
+int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st) {
+    if (L.sb) {
+        if (L.tpg == 12 && L.maxt == 640) return launch_b<12, 640, true>(L, a, B, st);
+        if (L.tpg == 8 && L.maxt == 1024) return launch_b<8, 1024, true>(L, a, B, st);
+        mg_set_error("lds: single-buffer mode exists for TPG 12 (<= 640 threads) and TPG 8 only");
+        return MGADMM_ERR_UNSUPPORTED;
+    }
+    if (L.maxt == 640 && L.tpg == 12) return launch_b<12, 640, false>(L, a, B, st);
+    switch (L.tpg) {
+        case 1: return launch_b<1, 1024, false>(L, a, B, st);
+        case 2: return launch_b<2, 1024, false>(L, a, B, st);
+        case 3: return launch_b<3, 1024, false>(L, a, B, st);
+        case 4: return launch_b<4, 1024, false>(L, a, B, st);
+        case 6: return launch_b<6, 1024, false>(L, a, B, st);
+        case 8: return launch_b<8, 1024, false>(L, a, B, st);
+        case 12: return launch_b<12, 1024, false>(L, a, B, st);
+    }
+    mg_set_error("lds: no kernel for TPG %d", L.tpg);
+    return MGADMM_ERR_UNSUPPORTED;
+}
+
+int mg_lds_init(bool masked, int T, int t_in, int N, int B, float tm, float den, const float* y, const float* mask, float* x,
+                float* zu, float* zd, float* gam, float* gu, float* gd, int* nonfinite, hipStream_t st) {
+    dim3 grid((N + 255) / 256, B);
+    if (masked) hipLaunchKernelGGL((k_init_lds<true>), grid, dim3(256), 0, st, T, t_in, N, B, tm, den, y, mask, x, zu, zd, gam, gu, gd, nonfinite);
+    else hipLaunchKernelGGL((k_init_lds<false>), grid, dim3(256), 0, st, T, t_in, N, B, tm, den, y, (const float*)nullptr, x, zu, zd, gam, gu, gd, nonfinite);
+    MG_HIP(hipGetLastError());
+    return MGADMM_OK;
+}
+
+int mg_lds_dxps(int T, int N, int B, const float* x, const float* xo, double* scratch, double* out, hipStream_t st) {
+    const int TN = T * N, nsl = (B + 63) / 64;
+    hipLaunchKernelGGL(k_dxps_sm, dim3((TN + 255) / 256, nsl), dim3(256), 0, st, TN, B, x, xo, scratch + TN);
+    hipLaunchKernelGGL(k_dxps_sm_mean, dim3((TN + 255) / 256), dim3(256), 0, st, TN, B, nsl, (const double*)(scratch + TN), scratch);
+    hipLaunchKernelGGL(k_dxps_sm_final, dim3(T), dim3(256), 0, st, T, N, (const double*)scratch, out);
+    MG_HIP(hipGetLastError());
+    return MGADMM_OK;
+}

@@ -190,6 +190,8 @@ __global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __re
             S selfc = S(1);
             if (op.self_mode == SELF_LDR) selfc = (t >= 1) ? S(1) : S(0);
             else if (op.self_mode == SELF_LDRT) selfc = (t > 0 || op.q1) ? S(1) : S(0);
+            else if (op.self_mode == SELF_LN_FATHER) selfc = (t + 1 < g.T) ? S(1) : S(0);
+            const S selft = selfc;
             const S* gbase = in + (size_t)(tvalid ? ts : t) * g.N * g.Bp + col0;   // slice the gathers read
             const S* obase = in + (size_t)t * g.N * g.Bp + col0;                  // slice of the rows we own
             RowMeta<GW> cur, nxt;
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __re
             if (!tvalid) ne1 = ne0;
             for (; i < n1; i += 4) {
                 const size_t roff = (size_t)i * g.Bp;
+                if (op.self_w) selfc = selft * (S)op.self_w[i];     // apply_op_Ln: row sum of d_ew as self coefficient
                 Vec<S, VEC> sum;
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) sum.v[v] = S(0);
@@ -528,6 +531,272 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) o.v[v] = ((acc[rr][v] + sm[0][v][lane]) + sm[1][v][lane]) + sm[2][v][lane];
                 stv<S, VEC>(partials + ((size_t)rr * g.P + slot) * g.Bp + col0, o);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Fused cLdr kernel: l = Ldr^T(Ldr x) in ONE pass over x (reference ADMM.py:225-228; the operator inside LHS_x and
+// LHS_zd, i.e. inside two of the three CG solves of every ADMM iteration).  The two-pass form writes q = Ldr x to
+// HBM and reads it back (8 B/element) and fetches the halo of both operators; here q never leaves the CU.
+//
+// A workgroup (NW waves) owns a tile of up to NW*MA consecutive node rows (one cluster of the node order) of one
+// 64*VECT-column chunk and sweeps t = 0 .. T-1.  For the step t it holds in LDS
+//     P = x_t      on C2 = C1 u {W_d neighbours of C1}      (2-hop set, <= NW*MP rows)
+//     Q = q_{t+1}  on C1 = tile u {W_d^T neighbours of it}  (1-hop set, <= NW*MQ rows), q = Ldr x recomputed on the halo
+// and in registers x_{t+1} of its C2 rows (requested one step ahead), x_t and q_t of its own rows:
+//     phase A   q_{t+1}[j] = x_{t+1}[j] - sum_e W_d[j,e] P[col_e]            for its rows j of C1   -> Q
+//     barrier
+//     phase C   P <- x_{t+1};  request x_{t+2};
+//               l_t[i] = [t>0 or q1] q_t[i] - sum_e W_d^T[i,e] Q[col_e]      for its own rows i     -> epilogue
+//     barrier
+// Local row l of a tile belongs to wave l % NW for all three roles, so the self terms are already in that wave's
+// registers.  Per-row (local column, weight) slots live in VGPR lanes and are broadcast with v_readlane exactly like
+// in k_tile (tables built on the host by build_cldr_tiles, cldr_tiles.h, which has a CPU replay test).  Sums run in
+// CSR entry order and q is rounded to S like the stored q of the two-pass form: the result is BITWISE the same.
+// ---------------------------------------------------------------------------------------------
+struct CldrGeom {
+    int T, N, B, Bp;
+    int CH;           // column chunks of 64*VECT
+    int NT;           // tiles
+    int TPX;          // tile slots per XCD = ceil(NT / 8)
+    int P;            // partial rows per column = 8 * TPX
+    int grid;         // 8 * TPX * CH workgroups
+    int tile_major;   // 1: consecutive workgroups of an XCD take consecutive TILES of one chunk (shared halos stay hot in
+                      //    its L2); 0: consecutive workgroups take the CHUNKS of one tile (whole rows are consumed together)
+    int q1;           // quirk Q1 self coefficient at t = 0 (immaterial: q_0 = 0)
+    int lds_bytes;
+};
+struct CldrMeta {
+    const int* n0;     // [NT+1]
+    const int* nC;     // [NT][2]  |C1|, |C2|
+    const int* rows;   // [NT][C2cap]
+    const int* dcol;   // [NT][C1cap][GD]
+    const float* dw;
+    const int* dcnt;   // [NT][C1cap]
+    const int* tcol;   // [NT][Rcap][GT]
+    const float* tw;
+    const int* tcnt;   // [NT][Rcap]
+};
+
+// sum_e w_e * IMG[col_e] for one row whose slots sit in lanes [slot0, slot0 + G) of the metadata registers;
+// pairs of slots past the first are skipped when the row has no entry there (wave-uniform)
+template <typename S, int VECT, int G, int K>
+__device__ __forceinline__ Vec<S, VECT> cldr_gather(const S* __restrict__ img_lane, const int (&mc)[K], const int (&mw)[K], int slot0, int cnt) {
+    Vec<S, VECT> sum;
+#pragma unroll
+    for (int v = 0; v < VECT; ++v) sum.v[v] = S(0);
+#pragma unroll
+    for (int u0 = 0; u0 < G; u0 += 2) {
+        if (u0 == 0 || cnt > u0) {
+            constexpr int GB = 2;
+            Vec<S, VECT> nv[GB];
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                if (u0 + u < G) {
+                    const int s = slot0 + u0 + u;
+                    const int lc = __builtin_amdgcn_readlane(mc[s >> 6], s & 63);
+                    nv[u] = ldv<S, VECT>(img_lane + lc);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GB; ++u) {
+                if (u0 + u < G) {
+                    const int s = slot0 + u0 + u;
+                    const S w = (S)__int_as_float(__builtin_amdgcn_readlane(mw[s >> 6], s & 63));
+#pragma unroll
+                    for (int v = 0; v < VECT; ++v) sum.v[v] = fma(w, nv[u].v[v], sum.v[v]);   // explicit: one rounding, like k_tile
+                }
+            }
+        }
+    }
+    return sum;
+}
+
+template <typename S, int VECT, class Epi, int NW, int MA, int MQ, int MP, int GD, int GT>
+__global__ __launch_bounds__(NW * 64) void k_cldr(CldrGeom g, CldrMeta m, const S* __restrict__ in, Epi epi_in,
+                                                  S* __restrict__ partials, const int* __restrict__ live) {
+    static_assert(MA <= MQ && MQ <= MP && MP <= 64, "own rows are a prefix of C1, C1 a prefix of C2");
+    extern __shared__ __align__(16) unsigned char cldr_raw[];
+    if (live != nullptr && *live == 0) return;
+    constexpr int W = 64 * VECT;
+    constexpr int RCAP = NW * MA, C1CAP = NW * MQ, C2CAP = NW * MP;
+    constexpr int KD = (MQ * GD + 63) / 64, KT = (MA * GT + 63) / 64;
+    S* Pimg = reinterpret_cast<S*>(cldr_raw);          // [C2CAP][W]
+    S* Qimg = Pimg + (size_t)C2CAP * W;                // [C1CAP][W]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xcd = blockIdx.x & 7;
+    const int qq = blockIdx.x >> 3;
+    int chunk, r;
+    if (g.tile_major) { r = qq % g.TPX; chunk = qq / g.TPX; }
+    else { chunk = qq % g.CH; r = qq / g.CH; }
+    const int tidx = xcd * g.TPX + r;
+    const bool tile_ok = tidx < g.NT;                  // the grid is padded to 8 * TPX tiles
+    const int col0 = (chunk * 64 + lane) * VECT;
+
+    int n0 = 0, R = 0, nC1 = 0;
+    int hrow = -1, dcn = 0, tcn = 0;
+    int mdc[KD], mdw[KD], mtc[KT], mtw[KT];
+#pragma unroll
+    for (int k = 0; k < KD; ++k) mdc[k] = mdw[k] = 0;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) mtc[k] = mtw[k] = 0;
+    if (tile_ok) {
+        n0 = m.n0[tidx];
+        R = m.n0[tidx + 1] - n0;
+        nC1 = m.nC[2 * tidx];
+        if (lane < MP) hrow = m.rows[(size_t)tidx * C2CAP + wave + NW * lane];       // -1 past |C2|
+        if (lane < MQ) dcn = m.dcnt[(size_t)tidx * C1CAP + wave + NW * lane];
+        if (lane < MA) tcn = m.tcnt[(size_t)tidx * RCAP + wave + NW * lane];
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            const int s = k * 64 + lane, mm = s / GD, u = s - mm * GD;
+            if (mm < MQ) {
+                const size_t o = ((size_t)tidx * C1CAP + wave + NW * mm) * GD + u;
+                mdc[k] = m.dcol[o] * W;
+                mdw[k] = __float_as_int(m.dw[o]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const int s = k * 64 + lane, mm = s / GT, u = s - mm * GT;
+            if (mm < MA) {
+                const size_t o = ((size_t)tidx * RCAP + wave + NW * mm) * GT + u;
+                mtc[k] = m.tcol[o] * W;
+                mtw[k] = __float_as_int(m.tw[o]);
+            }
+        }
+    }
+
+    Epi epi = epi_in;
+    epi.begin(col0);
+    constexpr int NR = Epi::NRED > 0 ? Epi::NRED : 1;
+    S acc[NR][VECT];
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr)
+#pragma unroll
+        for (int v = 0; v < VECT; ++v) acc[rr][v] = S(0);
+
+    if (tile_ok) {
+        const S* pl = Pimg + lane * VECT;
+        const S* ql = Qimg + lane * VECT;
+        const size_t slice = (size_t)g.N * g.Bp;
+        Vec<S, VECT> pn[MP];            // x_{t+1} of this wave's rows of C2 (requested one step ahead)
+        Vec<S, VECT> pc[MA], qp[MA];    // x_t and q_t of its own rows
+        // prologue: x_0 -> P image, q_0 = 0, request x_1
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            const int hr = __builtin_amdgcn_readlane(hrow, k);
+            if (hr >= 0) pn[k] = ldv<S, VECT>(in + (size_t)hr * g.Bp + col0);
+        }
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            const int hr = __builtin_amdgcn_readlane(hrow, k);
+            if (hr >= 0) stl<S, VECT>(Pimg + (size_t)(wave + NW * k) * W + lane * VECT, pn[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < MA; ++k) {
+            pc[k] = pn[k];
+#pragma unroll
+            for (int v = 0; v < VECT; ++v) qp[k].v[v] = S(0);
+        }
+        if (g.T > 1) {
+#pragma unroll
+            for (int k = 0; k < MP; ++k) {
+                const int hr = __builtin_amdgcn_readlane(hrow, k);
+                if (hr >= 0) pn[k] = ldv<S, VECT>(in + slice + (size_t)hr * g.Bp + col0);
+            }
+        }
+        __syncthreads();
+        for (int t = 0; t < g.T; ++t) {
+            const bool nxt = t + 1 < g.T;
+            Vec<S, VECT> qn[MA];
+            // ---- phase A: q_{t+1} on this wave's rows of C1
+            if (nxt) {
+#pragma unroll
+                for (int k = 0; k < MQ; ++k) {
+                    const int l = wave + NW * k;
+                    if (l < nC1) {
+                        const Vec<S, VECT> sum = cldr_gather<S, VECT, GD, KD>(pl, mdc, mdw, k * GD, __builtin_amdgcn_readlane(dcn, k));
+                        Vec<S, VECT> qv;
+#pragma unroll
+                        for (int v = 0; v < VECT; ++v) qv.v[v] = S(1) * pn[k].v[v] - sum.v[v];
+                        stl<S, VECT>(Qimg + (size_t)l * W + lane * VECT, qv);
+                        if (k < MA) qn[k] = qv;
+                    }
+                }
+            }
+            __syncthreads();                              // Q complete; every gather from P is done
+            // ---- phase C: P <- x_{t+1}, request x_{t+2}, own rows of l_t through the epilogue
+            Vec<S, VECT> pcn[MA];
+            if (nxt) {
+#pragma unroll
+                for (int k = 0; k < MP; ++k) {
+                    const int hr = __builtin_amdgcn_readlane(hrow, k);
+                    if (hr >= 0) stl<S, VECT>(Pimg + (size_t)(wave + NW * k) * W + lane * VECT, pn[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < MA; ++k) pcn[k] = pn[k];
+            }
+            if (t + 2 < g.T) {
+                const S* nb = in + (size_t)(t + 2) * slice + col0;
+#pragma unroll
+                for (int k = 0; k < MP; ++k) {
+                    const int hr = __builtin_amdgcn_readlane(hrow, k);
+                    if (hr >= 0) pn[k] = ldv<S, VECT>(nb + (size_t)hr * g.Bp);
+                }
+            }
+            const S selfc = (t > 0 || g.q1) ? S(1) : S(0);
+#pragma unroll
+            for (int k = 0; k < MA; ++k) {
+                const int l = wave + NW * k;
+                if (l < R) {
+                    Vec<S, VECT> sum;
+#pragma unroll
+                    for (int v = 0; v < VECT; ++v) sum.v[v] = S(0);
+                    if (nxt) sum = cldr_gather<S, VECT, GT, KT>(ql, mtc, mtw, k * GT, __builtin_amdgcn_readlane(tcn, k));
+                    Vec<S, VECT> lv;
+#pragma unroll
+                    for (int v = 0; v < VECT; ++v) lv.v[v] = selfc * qp[k].v[v] - sum.v[v];
+                    const size_t off = ((size_t)t * g.N + n0 + l) * g.Bp + col0;
+                    epi.row(t, off, pc[k], lv, acc);
+                }
+            }
+            if (nxt) {
+#pragma unroll
+                for (int k = 0; k < MA; ++k) {
+                    pc[k] = pcn[k];
+                    qp[k] = qn[k];
+                }
+            }
+            __syncthreads();                              // P = x_{t+1} complete; every gather from Q is done
+        }
+    }
+
+    if (Epi::NRED > 0) {
+        __syncthreads();
+        S(*sm)[VECT][64] = reinterpret_cast<S(*)[VECT][64]>(cldr_raw);   // the images are dead now
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) {
+            if (wave > 0) {
+#pragma unroll
+                for (int v = 0; v < VECT; ++v) sm[wave - 1][v][lane] = acc[rr][v];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                Vec<S, VECT> o;
+#pragma unroll
+                for (int v = 0; v < VECT; ++v) {
+                    S a = acc[rr][v];
+#pragma unroll
+                    for (int w2 = 0; w2 < NW - 1; ++w2) a += sm[w2][v][lane];
+                    o.v[v] = a;
+                }
+                stv<S, VECT>(partials + ((size_t)rr * g.P + tidx) * g.Bp + col0, o);
             }
             __syncthreads();
         }
@@ -955,8 +1224,11 @@ struct FinCgBeta {  // beta = rr'/rr ; convergence sqrt(rr') < tol ; (ADMM.py:35
     CgScalars<S> c;
     int k, Bp;
     double tol;
+    int batch_max;   // 1: the reference's batch-global stop (ADMM.py:360) -- a sample below the tolerance keeps iterating
+                     // until all are; n_active[k] then counts the samples still ABOVE it (0 = the solve has stopped)
     __device__ void operator()(int col, const double* s) const {
         bool act = c.active[col] != 0;
+        bool above = false;
         S b = S(0);
         if (act) {
             const S rrn = (S)s[0];
@@ -968,16 +1240,67 @@ struct FinCgBeta {  // beta = rr'/rr ; convergence sqrt(rr') < tol ; (ADMM.py:35
                 c.active[col] = 0;
                 act = false;
             } else if ((double)sqrt(rrn) < tol) {
-                c.iters[col] = k + 1;
-                c.active[col] = 0;
-                act = false;
+                if (!batch_max) {
+                    c.iters[col] = k + 1;
+                    c.active[col] = 0;
+                    act = false;
+                }
+            } else {
+                above = true;
             }
         } else if (c.beta_hist) {
             c.beta_hist[(size_t)k * Bp + col] = (S)NAN;
         }
         c.beta[col] = act ? b : S(0);
-        const unsigned long long m = __ballot(act);
+        const unsigned long long m = __ballot(batch_max ? above : act);
         if ((threadIdx.x & 63) == 0 && m) atomicAdd(&c.n_active[k], __popcll(m));
+    }
+};
+
+// batch_max: the iteration count of the whole solve = first k with n_active[k] == 0 (+1), -1 when never reached
+static __global__ void k_cg_batchmax_iters(const int* __restrict__ n_active, int K, int* __restrict__ iters, int B) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= B) return;
+    int it = -1;
+    for (int k = 0; k < K; ++k)
+        if (n_active[k] == 0) { it = k + 1; break; }
+    iters[col] = it;
+}
+
+// apply_op_Ln on the line graph (ADMM.py:253-261): y[t] = x[t] - x[t+1]/sqrt(2) for t < T-1, y[T-1] = x[T-1] - x[T-2]/sqrt(2)
+template <typename S, int VEC>
+struct EpiLnLine {
+    static constexpr bool ELEMENTWISE = true;
+    static constexpr int NRED = 0;
+    static constexpr bool HAS_PRE = false;
+    const S* x;
+    S* out;
+    int T;
+    size_t slice;     // N * Bp
+    __device__ void begin(int) {}
+    __device__ void row(int t, size_t off, const Vec<S, VEC>& self, const Vec<S, VEC>&, S (*)[VEC]) {
+        const Vec<S, VEC> nb = ldv<S, VEC>(t + 1 < T ? x + off + slice : x + off - slice);
+        Vec<S, VEC> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.v[v] = self.v[v] - nb.v[v] / (S)1.4142135623730951;
+        stv<S, VEC>(out + off, o);
+    }
+};
+
+// out = add + l
+template <typename S, int VEC>
+struct EpiAddTo {
+    static constexpr int NRED = 0;
+    static constexpr bool HAS_PRE = false;
+    const S* add;
+    S* out;
+    __device__ void begin(int) {}
+    __device__ void row(int, size_t off, const Vec<S, VEC>&, const Vec<S, VEC>& l, S (*)[VEC]) {
+        const Vec<S, VEC> a = ldv<S, VEC>(add + off);
+        Vec<S, VEC> o;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) o.v[v] = a.v[v] + l.v[v];
+        stv<S, VEC>(out + off, o);
     }
 };
 
@@ -996,7 +1319,7 @@ struct FinMetrics {
 
 // whole-batch value of every metric for this ADMM iteration (fixed summation order over samples):
 // norms -> sqrt(sum_b), regularisers -> mean_b      (ADMM.py:612-637, 230-246)
-__global__ void k_batch_metrics(const double* __restrict__ ps, int Bp, int B, double* __restrict__ out,
+static __global__ void k_batch_metrics(const double* __restrict__ ps, int Bp, int B, double* __restrict__ out,
                                 double* __restrict__ out_ps /* [NMETRIC][B] or nullptr */) {
     const int m = blockIdx.x;
     __shared__ double sm[256];
@@ -1043,7 +1366,7 @@ __global__ __launch_bounds__(256) void k_dxps(int T, int N, int Bp, int B, int N
     if (threadIdx.x == 0) part[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
 }
 
-__global__ void k_dxps_final(int T, int NBK, const double* __restrict__ part, double* __restrict__ out) {
+static __global__ void k_dxps_final(int T, int NBK, const double* __restrict__ part, double* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     double s = 0.0;

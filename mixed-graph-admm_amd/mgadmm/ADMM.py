@@ -59,12 +59,19 @@ class ADMM_algorithm():
       graph_backend   where the kNN search and the weight tables are computed: 'host' (NumPy, like the
                       reference's set-up code), 'gpu' (mgadmm.gpu_graph: HIP kernels) or 'auto' (gpu for
                       N >= 2048, where the host search takes seconds to minutes)
+      cg_convergence  'per_sample' (default): every sample of a batch stops its CG on its own residual, i.e. B samples
+                      are B independent reference runs; 'batch_max': the reference's literal test
+                      ``sqrt(rr).max() < CG_tol`` (ADMM.py:360) -- all samples iterate until the largest residual of
+                      the batch is below the tolerance (streaming kernels only; one count per solve)
     """
 
     def __init__(self, graph_info, ADMM_info, use_kNN=False, k=4, u_sigma=None, d_sigma=None, expand_time_dim=True,
                  ablation='None', t_in=12, T=24, use_line_graph=False, skip_connection=1, *, device=None,
                  compute_dtype=torch.float32, bug_compat=True, tables=None, reorder='auto', record_cg_coeffs='auto',
-                 path='auto', graph_backend='auto'):
+                 path='auto', graph_backend='auto', cg_convergence='per_sample'):
+        if cg_convergence not in ('per_sample', 'batch_max'):
+            raise ValueError(f"cg_convergence must be 'per_sample' or 'batch_max', got {cg_convergence!r}")
+        self.cg_convergence = cg_convergence
         if graph_backend not in ('auto', 'host', 'gpu'):
             raise ValueError(f"graph_backend must be 'auto', 'host' or 'gpu', got {graph_backend!r}")
         if graph_backend == 'auto':
@@ -139,7 +146,11 @@ class ADMM_algorithm():
         self.DGTV_list, self.DGLR_list, self.GLR_list, self.recover_list = [], [], [], []
 
     def init_iterations(self, ablation, use_line_graph=False):
-        """Reset the history and switch ablation / temporal graph (ADMM.py:100-133)."""
+        """Reset the history and switch ablation / temporal graph (ADMM.py:100-133).  Like the reference: the history
+        lists are cleared EXCEPT ``recover_list`` (the reference never resets it, ADMM.py:100-133), the line graph is
+        rebuilt with skip_connection = 1 (ADMM.py:104-106: ``ones((N, T, 1))`` whatever the constructor's skip was)
+        and the kNN-directed weights are rebuilt with the default sigma (ADMM.py:108: no ``d_sigma`` argument)."""
+        keep_recover = self.recover_list
         if use_line_graph:
             self.use_line_graph = True
             self.skip_connection = 1
@@ -151,6 +162,7 @@ class ADMM_algorithm():
         assert ablation in ['None', 'DGTV', 'DGLR', 'UT']
         self.ablation = ablation
         self._reset_history()
+        self.recover_list = keep_recover
         self._set_res_name()
         self.close()
 
@@ -174,8 +186,21 @@ class ADMM_algorithm():
 
     # ------------------------------------------------------------------ handles
     def _table_key(self):
-        return (id(self.connect_list), id(self.u_ew), id(self.d_ew), self.use_line_graph, self.skip_connection,
+        # identity AND in-place version of every table: `blk.u_ew = ...` and `blk.u_ew.mul_(2)` both rebuild the device CSR
+        tv = lambda t: (id(t), getattr(t, "_version", 0), tuple(t.shape))
+        return (tv(self.connect_list), tv(self.u_ew), tv(self.d_ew), self.use_line_graph, self.skip_connection,
                 self.use_kNN, self.bug_compat, self.T)
+
+    @staticmethod
+    def _time_invariant(tab, name):
+        """The device CSR holds ONE spatial slice: the reference's (T, N, k) tables are pure repeats of it
+        (utils.py:294-295).  A table that really varies over time would be silently collapsed -- refuse it."""
+        if tab.dim() == 3:
+            if tab.shape[0] > 1 and not bool((tab == tab[0:1]).all()):
+                raise NotImplementedError(f"{name} varies over the time axis; only time-expanded repeats of one (N, k) table "
+                                          "(expand_time_dimension, utils.py:294-295) are supported")
+            return tab[0]
+        return tab
 
     def _graph(self, Cn):
         key = self._table_key()
@@ -186,7 +211,7 @@ class ADMM_algorithm():
             for k2 in [k2 for k2 in self._solvers if k2[0] == Cn]:
                 _lib.lib.mgadmm_solver_destroy(self._solvers.pop(k2)[0])
             ent[0].close()
-        u_ew = self.u_ew[0] if self.u_ew.dim() == 3 else self.u_ew
+        u_ew = self._time_invariant(self.u_ew, "u_ew")
         u_csr = expand_channels(tables_to_csr(self.connect_list, u_ew, 1), Cn)
         N = self.n_nodes * Cn
         reorder = self.reorder
@@ -199,7 +224,7 @@ class ADMM_algorithm():
             gph = Graph(N, self.T, u_csr, None, band_w=bw, skip=self.skip_connection, reorder=reorder,
                         device=dev.index or 0)
         else:
-            d_ew = self.d_ew[0] if self.d_ew.dim() == 3 else self.d_ew
+            d_ew = self._time_invariant(self.d_ew, "d_ew")
             d_csr = expand_channels(tables_to_csr(self.connect_list, d_ew, 0), Cn)
             gph = Graph(N, self.T, u_csr, d_csr, transpose_by_gather=not self.use_kNN,
                         q1_identity_t0=self.bug_compat, reorder=reorder, device=dev.index or 0)
@@ -221,6 +246,8 @@ class ADMM_algorithm():
         if rec == 'auto':
             rec = B <= 64
         p.record_cg_coeffs = int(bool(rec))
+        p.cg_convergence = _lib.CG_BATCH_MAX if self.cg_convergence == 'batch_max' else _lib.CG_PER_SAMPLE
+        p.max_inner_iter = int(self.max_inner_iter)
         return p
 
     def _solver(self, Cn, dtype, B):
@@ -279,8 +306,9 @@ class ADMM_algorithm():
         return self._run_tensor_op("mgadmm_apply", x, pre=(_lib.OP_CLDR,))
 
     def apply_op_Ln(self, x):
-        raise NotImplementedError("apply_op_Ln is unreachable in the reference (LHS_zd's 'UT' branch is shadowed, "
-                                  "ADMM.py:393-396) and is out of scope here")
+        """Undirected temporal Laplacian (ADMM.py:248-288; unreachable from the reference's own solver: the 'UT' branch
+        of LHS_zd is shadowed, ADMM.py:393-396)."""
+        return self._run_tensor_op("mgadmm_apply", x, pre=(_lib.OP_LN,))
 
     # ------------------------------------------------------------------ left-hand sides (ADMM.py:371-399)
     def LHS_x(self, x, mask=None):
@@ -350,12 +378,57 @@ class ADMM_algorithm():
 
     # ------------------------------------------------------------------ the ADMM loop (ADMM.py:511-648)
     def two_loops(self, y, mask=None, differential=False):
-        raise NotImplementedError("two_loops is a dead experiment in the reference (returns None, records "
-                                  "nothing, ADMM.py:410-508); use combined_loop")
+        """The reference's two-loops variant (ADMM.py:410-508): ``max_ADMM_iter`` outer phi / gamma updates around
+        ``max_inner_iter`` inner (x, zu, zd, gamma_u, gamma_d) updates restarted in every outer iteration.  Like the
+        reference it returns None and appends the CG counts of every inner iteration to ``CG_iter_x/zu/zd``; the final
+        iterate is kept in ``self.state`` (x, zu, zd, phi, gamma, gamma_u, gamma_d)."""
+        if differential:
+            assert mask is None, 'differential mode does not support mask'
+        dt = self._dtype_for(y)
+        yd = self._dev_tensor(y, dt, "y", self.t_in if mask is None else self.T)
+        B, _, N, Cn = yd.shape
+        md, mask_f32 = None, 0
+        if mask is not None:
+            if tuple(mask.shape) != tuple(y.shape):
+                raise ValueError(f"mask shape {tuple(mask.shape)} != y shape {tuple(y.shape)}")
+            mask_f32 = int(mask.dtype == torch.float32)
+            md = self._dev_tensor(mask, dt, "mask", self.T)
+        h, p = self._solver(Cn, dt, B)
+        x = torch.empty((B, self.T, N, Cn), device=yd.device, dtype=dt)
+        has_phi, has_zd = self.ablation in ('None', 'DGLR'), self.ablation != 'DGLR'
+        st, state = _lib.State(), {}
+        for nm in ("zu", "zd", "phi", "gamma", "gamma_u", "gamma_d"):
+            if nm in ("phi", "gamma") and not has_phi:
+                continue
+            state[nm] = torch.empty_like(x)
+            setattr(st, nm, state[nm].data_ptr())
+        rows = p.max_admm_iter * p.max_inner_iter
+        cg_it = np.zeros((rows, 3, B), dtype=np.int32)
+        hs = _lib.History()
+        hs.cg_iters = cg_it.ctypes.data_as(C.POINTER(C.c_int32))
+        rc = _lib.lib.mgadmm_two_loops(h, _ptr(yd), _ptr(md), mask_f32, B, _ptr(x), C.byref(st), C.byref(hs), _stream_ptr(yd.device))
+        if rc == _lib.ERR_NONFINITE:
+            raise AssertionError("NaN/Inf value in the two_loops iterates (reference asserts, ADMM.py:432-504): "
+                                 + _lib.lib.mgadmm_last_error().decode())
+        _lib.check(rc)
+        for i in range(rows):
+            for w, lst in ((0, self.CG_iter_x), (1, self.CG_iter_zu), (2, self.CG_iter_zd)):
+                if w == 2 and not has_zd:
+                    continue
+                lst.append(int(cg_it[i, w, 0]) if B == 1 else torch.from_numpy(cg_it[i, w].astype(np.int64)))
+        back = lambda t: t.to(device=y.device, dtype=y.dtype)
+        self.state = {k2: back(v) for k2, v in state.items()}
+        self.state["x"] = back(x)
+        return None
 
-    def solve(self, y, mask=None, differential=False, print_info=False, return_state=True, per_sample_history=False):
+    def solve(self, y, mask=None, differential=False, print_info=False, return_state=True, per_sample_history=False,
+              warm_start=None):
         """Run the ADMM loop and return ``(x, (zu, zd), phi, history)``; ``history`` is a dict with the
-        same lists that are also stored on the instance (p_res_list, d_res_list, ...)."""
+        same lists that are also stored on the instance (p_res_list, d_res_list, ...).
+
+        ``warm_start``: a state dict as left in ``self.state`` by a previous ``solve`` (keys x, zu, gamma_u and, as the
+        ablation requires, zd, gamma_d, phi, gamma): the loop resumes from it instead of the initial guess
+        (checkpoint / resume; k1 + k2 iterations in two calls equal k1 + k2 iterations in one)."""
         if differential:
             assert mask is None, 'differential mode does not support mask'   # flag has no other effect (Q3)
         dt = self._dtype_for(y)
@@ -400,13 +473,35 @@ class ADMM_algorithm():
             be = np.full((I, 3, K, B), np.nan, dtype=np.float64)
             hs.cg_alpha = al.ctypes.data_as(C.POINTER(C.c_double))
             hs.cg_beta = be.ctypes.data_as(C.POINTER(C.c_double))
-        rc = _lib.lib.mgadmm_solve(h, _ptr(yd), _ptr(md), mask_f32, B, _ptr(x), C.byref(st), C.byref(hs),
-                                   _stream_ptr(dev))
-        if rc == _lib.ERR_NONFINITE:
-            raise AssertionError("NaN/Inf value in the ADMM iterates (reference asserts, ADMM.py:534-606): "
-                                 + _lib.lib.mgadmm_last_error().decode())
-        _lib.check(rc)
+        if warm_start is None:
+            rc = _lib.lib.mgadmm_solve(h, _ptr(yd), _ptr(md), mask_f32, B, _ptr(x), C.byref(st), C.byref(hs),
+                                       _stream_ptr(dev))
+        else:
+            need = ["x", "zu", "gamma_u"] + (["zd", "gamma_d"] if has_zd else []) + (["phi", "gamma"] if has_phi else [])
+            missing = [k2 for k2 in need if warm_start.get(k2) is None]
+            if missing:
+                raise ValueError(f"warm_start misses {missing} (ablation {self.ablation!r})")
+            win = {k2: self._dev_tensor(warm_start[k2], dt, "warm_start." + k2, self.T) for k2 in need}
+            if any(tuple(v.shape) != tuple(x.shape) for v in win.values()):
+                raise ValueError("warm_start tensors must have the shape of x (B, T, N, C)")
+            sin = _lib.State()
+            for nm in need[1:]:
+                setattr(sin, nm, win[nm].data_ptr())
+            rc = _lib.lib.mgadmm_solve_from(h, _ptr(yd), _ptr(md), mask_f32, B, _ptr(win["x"]), C.byref(sin), _ptr(x),
+                                            C.byref(st), C.byref(hs), _stream_ptr(dev))
         n = hs.n_iters
+        if rc == _lib.ERR_NONFINITE:
+            # like the reference at its asserts (ADMM.py:534-606), the history of the iterations that ran is available
+            self._fill_history(metrics[:n], dxps[:n], cg_it[:n], al, be, B, has_phi, has_zd, False)
+            bad = ""
+            if mps is not None:
+                self.metrics_per_sample = mps[:n]
+                idx = np.nonzero(~np.isfinite(mps[:n]).all(axis=(0, 1)))[0]
+                self.nonfinite_samples = idx
+                bad = f"; non-finite samples: {idx[:16].tolist()}{' ...' if idx.size > 16 else ''}"
+            raise AssertionError("NaN/Inf value in the ADMM iterates (reference asserts, ADMM.py:534-606): "
+                                 + _lib.lib.mgadmm_last_error().decode() + bad)
+        _lib.check(rc)
         self._fill_history(metrics[:n], dxps[:n], cg_it[:n], al, be, B, has_phi, has_zd, print_info)
         if mps is not None:
             self.metrics_per_sample = mps[:n]
@@ -416,6 +511,7 @@ class ADMM_algorithm():
         zd = back(state["zd"]) if "zd" in state else None
         phi = back(state["phi"]) if "phi" in state else None
         self.state = {k2: back(v) for k2, v in state.items()}
+        self.state["x"] = xo
         return xo, (zu, zd), phi, self.history()
 
     def combined_loop(self, y, mask=None, differential=False, print_info=True):

@@ -18,7 +18,8 @@ LIB_PATH = os.environ.get("MGADMM_LIB") or os.path.join(_HERE, "libmgadmm.so")
 OK, ERR_INVALID, ERR_HIP, ERR_NONFINITE, ERR_UNSUPPORTED, ERR_NOMEM = 0, -1, -2, -3, -4, -5
 F32, F64 = 0, 1
 TEMPORAL_SPATIAL, TEMPORAL_BAND = 0, 1
-OP_LU, OP_LDR, OP_LDRT, OP_CLDR = 0, 1, 2, 3
+OP_LU, OP_LDR, OP_LDRT, OP_CLDR, OP_LN = 0, 1, 2, 3, 4
+CG_PER_SAMPLE, CG_BATCH_MAX = 0, 1
 LHS_X, LHS_ZU, LHS_ZD = 0, 1, 2
 ABLATIONS = {"None": 0, "DGTV": 1, "DGLR": 2, "UT": 3}
 PATH_AUTO, PATH_STREAM, PATH_LDS = 0, 1, 2
@@ -52,7 +53,7 @@ class Params(C.Structure):
         ("cg_tol", C.c_double), ("max_cg_iter", C.c_int32),
         ("admm_tol", C.c_double), ("max_admm_iter", C.c_int32),
         ("dtype", C.c_int32), ("check_stop", C.c_int32), ("path", C.c_int32),
-        ("record_cg_coeffs", C.c_int32),
+        ("record_cg_coeffs", C.c_int32), ("cg_convergence", C.c_int32), ("max_inner_iter", C.c_int32),
     ]
 
 
@@ -92,6 +93,8 @@ SYMBOLS = {
     "mgadmm_initial_interpolation": (C.c_int, [_vp, _vp, _vp, C.c_int32, _vp, C.c_int32, _vp]),
     "mgadmm_cg": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _i32p, _f64p, _f64p, C.c_int32, _vp]),
     "mgadmm_solve": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, _vp, C.POINTER(State), C.POINTER(History), _vp]),
+    "mgadmm_solve_from": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, _vp, C.POINTER(State), _vp, C.POINTER(State), C.POINTER(History), _vp]),
+    "mgadmm_two_loops": (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, _vp, C.POINTER(State), C.POINTER(History), _vp]),
     "mgadmm_knn_graph": (C.c_int, [C.c_int32, C.c_int64, C.POINTER(C.c_int64), _f64p, C.c_int32, _i32p, _f32p, C.c_int32]),
     "mgadmm_weight_tables": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int64), _f32p, C.c_double, C.c_double, C.c_int32,
                                        _f32p, _f32p, _f64p, C.c_int32]),

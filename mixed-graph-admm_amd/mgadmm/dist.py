@@ -3,8 +3,17 @@
 Every sample is an independent optimisation (all CG reductions are per sample, reference
 ADMM.py:347-356), so the batch is cut into contiguous blocks, one per rank (one process per GPU,
 ``torch.distributed`` with backend "nccl" = RCCL over xGMI, or "gloo" on CPU for tests), the graph
-tables are replicated, and there is NO collective on the convergence path.  The only exchange is the
-final gather of the x shards (and of the per-shard residual history).
+tables are replicated, and there is NO collective on the convergence path.  The only exchanges are at the
+end: one gather of the x shards to the destination rank and one gather of the (tiny) per-shard residual
+history, from which the reference-style whole-batch norms are re-formed (``gather_history``).
+
+What sharding changes and what it does not
+  * iterates: nothing, for a fixed iteration count (``check_stop=False`` or the same ``max_ADMM_iter`` reached
+    everywhere) -- sample b's x is bitwise the x of the unsharded run;
+  * early stop: the reference's stop test (ADMM.py:645-646) uses whole-BATCH norms.  Without a collective per
+    iteration each shard can only test its own norms, so with ``check_stop=True`` a shard stops when ITS samples have
+    converged (never later than the whole batch would).  Use a fixed iteration count when bit-identical results
+    across different GPU counts matter; ``gather_history`` reports the iteration count of every shard.
 """
 import torch
 import torch.distributed as dist
@@ -17,33 +26,54 @@ def shard_bounds(B, world_size, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _gather_blocks(xs, n_local, width, tail, dtype, dev, ws, group, async_op):
-    """all_gather of one equal-size padded block per rank; returns (parts, work)."""
+def _world(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def _coll_device(group):
+    backend = dist.get_backend(group)
+    return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+
+def _exchange_blocks(xs, n_local, width, tail, dtype, dev, ws, rk, group, mode, dst, async_op):
+    """One equal-size padded block per rank -> every rank ('all') or the destination rank ('root').
+    Returns (parts or None, work)."""
     buf = torch.zeros((width,) + tail, dtype=dtype, device=dev)
     if xs is not None and n_local > 0:
         buf[:n_local] = xs.to(dev)
-    parts = [torch.empty_like(buf) for _ in range(ws)]
-    work = dist.all_gather(parts, buf, group=group, async_op=async_op)
+    if mode == "all":
+        parts = [torch.empty_like(buf) for _ in range(ws)]
+        work = dist.all_gather(parts, buf, group=group, async_op=async_op)
+        return parts, work
+    parts = [torch.empty_like(buf) for _ in range(ws)] if rk == dst else None
+    gdst = dist.get_global_rank(group, dst) if group is not None else dst
+    work = dist.gather(buf, parts, dst=gdst, group=group, async_op=async_op)
     return parts, work
 
 
-def sharded_solve(solve_fn, y, mask=None, *, gather=True, group=None, chunks=1):
-    """Run ``solve_fn(y_shard, mask_shard) -> x_shard`` on this rank's batch block and gather the shards.
+def sharded_solve(solve_fn, y, mask=None, *, gather="root", group=None, chunks=1, dst=0):
+    """Run ``solve_fn(y_shard, mask_shard) -> x_shard`` on this rank's batch block and collect the shards.
 
     ``solve_fn`` is normally ``ADMM_algorithm.combined_loop`` bound to a solver on this rank's GPU.
-    With ``gather=True`` every rank returns the full (B,T,N,C) tensor (all_gather of equal-size padded
-    blocks); with ``gather=False`` each rank returns only its block.  Works without an initialised
-    process group (world_size 1).
+      gather="root" (or True)  one gather to rank ``dst`` (the exchange BASELINE.json's north star names): rank ``dst``
+                               returns the full (B,T,N,C) tensor, every other rank returns None;
+      gather="all"             all_gather: every rank returns the full tensor (costs world_size x the memory);
+      gather=False             no exchange, each rank returns its own block.
+    Works without an initialised process group (world_size 1).
 
     ``chunks > 1`` cuts the rank's block into that many sub-blocks that are solved one after the other; the
-    all_gather of sub-block c is issued asynchronously (RCCL runs it on its own stream) and overlaps the solve
-    of sub-block c+1, so only the last sub-block's exchange is exposed.  Samples are independent, so the result
-    does not depend on ``chunks``.
+    exchange of sub-block c is issued asynchronously (RCCL runs it on its own stream) and overlaps the solve
+    of sub-block c+1, so only the last sub-block's exchange is exposed.  Samples are independent, so for a fixed
+    iteration count the result does not depend on ``chunks`` or on the number of ranks (see the module docstring
+    for early stopping).
     """
-    if dist.is_available() and dist.is_initialized():
-        ws, rk = dist.get_world_size(group), dist.get_rank(group)
-    else:
-        ws, rk = 1, 0
+    if gather is True:
+        gather = "root"
+    if gather not in ("root", "all", False):
+        raise ValueError(f"gather must be 'root', 'all' or False, got {gather!r}")
+    ws, rk = _world(group)
     B = y.shape[0]
     lo, hi = shard_bounds(B, ws, rk)
     chunks = max(1, int(chunks))
@@ -56,8 +86,7 @@ def sharded_solve(solve_fn, y, mask=None, *, gather=True, group=None, chunks=1):
             if b > a:
                 outs.append(solve_fn(y[lo + a:lo + b], mask[lo + a:lo + b] if mask is not None else None))
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    dev = _coll_device(group)
     width = (B + ws - 1) // ws                       # largest shard
     cwidth = (width + chunks - 1) // chunks          # largest sub-block of any rank
     pending = []                                     # (parts, work) per sub-block
@@ -78,16 +107,95 @@ def sharded_solve(solve_fn, y, mask=None, *, gather=True, group=None, chunks=1):
             first = next(s for s in shp if int(s[:3].sum()) > 0)
             tail = tuple(int(v) for v in first[:3].tolist())
             dtype = xs.dtype if xs is not None else (torch.float64 if int(first[3]) else torch.float32)
-        pending.append(_gather_blocks(xs, b - a, cwidth, tail, dtype, dev, ws, group, async_op=chunks > 1 and c < chunks - 1))
+        pending.append(_exchange_blocks(xs, b - a, cwidth, tail, dtype, dev, ws, rk, group, gather, dst,
+                                        async_op=chunks > 1 and c < chunks - 1))
+    for c in range(chunks):
+        parts, work = pending[c]
+        if work is not None:
+            work.wait()
+    if gather == "root" and rk != dst:
+        return None
     out = []
     for r in range(ws):
         l2, h2 = shard_bounds(B, ws, r)
         for c in range(chunks):
             a, b = shard_bounds(h2 - l2, chunks, c)
-            parts, work = pending[c]
-            if work is not None:
-                work.wait()
-                pending[c] = (parts, None)
             if b > a:
-                out.append(parts[r][: b - a])
-    return torch.cat(out, 0).to(y.device if backend != "nccl" else dev)
+                out.append(pending[c][0][r][: b - a])
+    return torch.cat(out, 0).to(y.device if dev.type == "cpu" else dev)
+
+
+# ---------------------------------------------------------------------------------------------- residual history
+_NORM_KEYS = ("p_res_list", "d_res_list", "x_shift_list", "recover_list")        # Frobenius norms over the batch
+_MEAN_KEYS = ("GLR_list", "DGTV_list", "DGLR_list")                             # means over the samples
+
+
+def _as_matrix(v):
+    if len(v) == 0:
+        return torch.zeros((0, 0), dtype=torch.float64)
+    t = torch.as_tensor([[float(e) for e in row] if isinstance(row, (list, tuple)) else [float(row)] for row in v],
+                        dtype=torch.float64)
+    return t
+
+
+def gather_history(history, n_local, *, group=None, dst=0):
+    """Whole-batch residual history of a sharded solve, re-formed on rank ``dst`` from the per-shard histories
+    (SURVEY.md 8e): norms combine as sqrt(sum_shards local^2) (ADMM.py:612-636 are Frobenius norms over the batch
+    tensor), regularisers (means over samples, ADMM.py:230-246) as sample-weighted means.  One gather of a few hundred
+    floats, after the loop -- nothing on the convergence path.
+
+    ``history`` is ``ADMM_algorithm.history()`` (or the instance itself) of this rank's solve of ``n_local`` samples.
+    Ranks may have executed different iteration counts (early stop is per shard): the combined lists cover the
+    iterations EVERY non-empty shard executed; ``iters_per_shard`` holds each shard's own count.  ``delta_x_per_step`` is
+    the norm of a batch MEAN (ADMM.py:614) and cannot be combined from shard norms: it is returned per shard.
+    Returns a dict on rank ``dst`` and None elsewhere.
+    """
+    get = (lambda k: history[k]) if isinstance(history, dict) else (lambda k: getattr(history, k))
+    ws, rk = _world(group)
+    mats = {k: _as_matrix(get(k)) for k in _NORM_KEYS + _MEAN_KEYS}
+    dxps = torch.stack([torch.as_tensor(v, dtype=torch.float64) for v in get("delta_x_per_step")]) \
+        if len(get("delta_x_per_step")) else torch.zeros((0, 0), dtype=torch.float64)
+    iters = mats["p_res_list"].shape[0]
+    if ws == 1:
+        out = {k: mats[k] for k in mats}
+        out.update(iters_per_shard=[iters], samples_per_shard=[n_local], delta_x_per_step_per_shard=[dxps])
+        return out
+    dev = _coll_device(group)
+    # fixed-size packet per rank: [n_local, iters, ncol per key..., payload padded to the longest]
+    cols = [mats[k].shape[1] if mats[k].numel() else 0 for k in mats] + [dxps.shape[1] if dxps.numel() else 0]
+    head = torch.tensor([n_local, iters] + cols, dtype=torch.float64)
+    body = torch.cat([mats[k].reshape(-1) for k in mats] + [dxps.reshape(-1)])
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
+    dist.all_gather(sizes, torch.tensor([head.numel() + body.numel()], dtype=torch.int64, device=dev), group=group)
+    width = int(max(int(s) for s in sizes))
+    pkt = torch.zeros(width, dtype=torch.float64, device=dev)
+    pkt[: head.numel() + body.numel()] = torch.cat([head, body]).to(dev)
+    parts = [torch.empty_like(pkt) for _ in range(ws)] if rk == dst else None
+    gdst = dist.get_global_rank(group, dst) if group is not None else dst
+    dist.gather(pkt, parts, dst=gdst, group=group)
+    if rk != dst:
+        return None
+    keys = list(mats)
+    shards = []
+    for p in parts:
+        p = p.cpu()
+        nl, it = int(p[0]), int(p[1])
+        cs = [int(v) for v in p[2:2 + len(keys) + 1]]
+        off = 2 + len(keys) + 1
+        d = {}
+        for k, c in zip(keys + ["delta_x_per_step"], cs):
+            d[k] = p[off: off + it * c].reshape(it, c) if c else torch.zeros((it, 0), dtype=torch.float64)
+            off += it * c
+        shards.append((nl, it, d))
+    live = [s for s in shards if s[0] > 0]
+    n_it = min(s[1] for s in live) if live else 0
+    total = sum(s[0] for s in live)
+    out = {}
+    for k in _NORM_KEYS:
+        out[k] = torch.sqrt(sum(s[2][k][:n_it] ** 2 for s in live)) if live else torch.zeros((0, 0))
+    for k in _MEAN_KEYS:
+        out[k] = sum(s[2][k][:n_it] * s[0] for s in live) / max(total, 1) if live else torch.zeros((0, 0))
+    out["iters_per_shard"] = [s[1] for s in shards]
+    out["samples_per_shard"] = [s[0] for s in shards]
+    out["delta_x_per_step_per_shard"] = [s[2]["delta_x_per_step"] for s in shards]
+    return out

@@ -18,6 +18,11 @@ Fixture groups:
   g5_batched    8 single-sample solves stacked                 (batched-parity definition, Q6)
   g6_kats       small literal known-answer vectors             (notebook / __main__ KATs)
   g7_dataset    TrafficDataset on synthetic files               (utils.py:54-134)
+  g8_ln         dense matrices of apply_op_Ln                    (ADMM.py:248-288)
+  g9_two_loops  two_loops runs: x / gamma / phi per outer iteration, captured at its phi_direct call, + CG counts
+                                                                 (ADMM.py:410-508; the method itself returns None)
+  g10_cg_batchmax  CG_solver on B = 8 samples with the reference's batch-global stop sqrt(rr).max() < tol
+                                                                 (ADMM.py:360; the method crashes at the stop for B > 1)
 """
 import contextlib
 import io
@@ -391,6 +396,106 @@ def g7_dataset():
     np.savez_compressed(os.path.join(OUT, "g7_dataset.npz"), **out)
 
 
+def g8_ln(n, edges, dist, k, sigma, T=6, t_in=3):
+    """apply_op_Ln (undirected temporal Laplacian, ADMM.py:248-288) as dense matrices for every graph mode it has a
+    branch for: kNN (scatter_add), physical (gather), line graph."""
+    gi = graph_info(n, edges, dist)
+    out = {}
+    for mode in ("knn", "physical", "line"):
+        a = build(gi, admm_info(n, T), mode, k, sigma, t_in=t_in, T=T)
+        out[mode + "_Ln"] = dense_of(a.apply_op_Ln, T, n)
+        out[mode + "_cl"] = a.connect_list.numpy()
+        if mode != "line":
+            out[mode + "_d_ew"] = a.d_ew[0].numpy()
+        out[mode + "_u_ew"] = a.u_ew[0].numpy()
+        torch.manual_seed(5)
+        x = torch.randn(3, T, n, 2, dtype=torch.float64)
+        out[mode + "_x"] = x.numpy()
+        out[mode + "_y"] = a.apply_op_Ln(x).numpy()
+    np.savez_compressed(os.path.join(OUT, "g8_ln.npz"), T=T, t_in=t_in, n=n, **out)
+
+
+def g9_two_loops(n, edges, dist, k, sigma, T=24, t_in=12):
+    """two_loops (ADMM.py:410-508) keeps everything in locals and returns None.  With ablation 'None' / 'DGLR' it
+    calls self.phi_direct(x, gamma) once per outer iteration, after the inner loop: wrapping that bound method captures
+    x (the iterate after max_inner_iter inner iterations), gamma (before its update) and the new phi; the CG counts are
+    appended to the instance lists.  'DGTV' has no such hook: only its CG counts are stored."""
+    gi = graph_info(n, edges, dist)
+    info = admm_info(n, T)
+    out = {}
+    y = synth_y(n, T, seed=3, dtype=torch.float64)[:, :t_in]
+    out["y"] = y.numpy()
+    for mode in ("knn", "line"):
+        for abl in ("None", "DGLR", "DGTV"):
+            a = build(gi, info, mode, k, sigma, ablation=abl, t_in=t_in, T=T)
+            a.max_ADMM_iter, a.max_inner_iter = 3, 4
+            cap = {"x": [], "gamma": [], "phi": []}
+            orig = a.phi_direct
+
+            def hook(x, gamma, _orig=orig, _cap=cap):
+                phi = _orig(x, gamma)
+                _cap["x"].append(x.clone().numpy()); _cap["gamma"].append(gamma.clone().numpy()); _cap["phi"].append(phi.clone().numpy())
+                return phi
+
+            a.phi_direct = hook
+            r = quiet(a.two_loops, y)
+            assert r is None
+            tag = f"{mode}_{abl}"
+            for kq, v in cap.items():
+                if v:
+                    out[f"{tag}_{kq}"] = np.stack(v)
+            out[f"{tag}_cg_x"] = np.asarray(a.CG_iter_x)
+            out[f"{tag}_cg_zu"] = np.asarray(a.CG_iter_zu)
+            if abl != "DGLR":
+                out[f"{tag}_cg_zd"] = np.asarray(a.CG_iter_zd)
+            if mode == "knn" and abl == "None":
+                out["cl"], out["u_ew"], out["d_ew"] = a.connect_list.numpy(), a.u_ew[0].numpy(), a.d_ew[0].numpy()
+    for key in ("rho", "rho_u", "rho_d", "mu_u", "mu_d1", "mu_d2"):
+        out[key] = info[key]
+    np.savez_compressed(os.path.join(OUT, "g9_two_loops.npz"), T=T, t_in=t_in, n=n, max_outer=3, max_inner=4, **out)
+
+
+def g10_cg_batchmax(n, edges, dist, k, sigma, T=6, t_in=3, B=8):
+    """The reference's CG stop is batch-global: `torch.sqrt(r_norm_sq).max() < CG_tol` (ADMM.py:360).  For B > 1 the
+    method raises at that very return (torch.Tensor(list of (B,) tensors), ADMM.py:362), but it returns normally
+    (x, -1, lists) when max_CG_iter runs out first.  So: K* = the smallest max_CG_iter at which the call raises = the
+    iteration of the batch-global stop; the iterates at that point come from a run with CG_tol = 0 (never stops) and
+    max_CG_iter = K*: same arithmetic, x after K* iterations, every alpha / beta of every sample."""
+    gi = graph_info(n, edges, dist)
+    out = {}
+    a = build(gi, admm_info(n, T), "knn", k, sigma, t_in=t_in, T=T)
+    torch.manual_seed(13)
+    scale = torch.logspace(-1, 2, B, dtype=torch.float64).reshape(B, 1, 1, 1)     # samples converge at different iterations
+    rhs = torch.randn(B, T, n, 1, dtype=torch.float64) * scale
+    x0 = torch.randn(B, T, n, 1, dtype=torch.float64)
+    out["rhs"], out["x0"] = rhs.numpy(), x0.numpy()
+    out["cl"], out["u_ew"], out["d_ew"] = a.connect_list.numpy(), a.u_ew[0].numpy(), a.d_ew[0].numpy()
+    for nm, fn in (("x", a.LHS_x), ("zu", a.LHS_zu), ("zd", a.LHS_zd)):
+        kstar = None
+        for m in range(1, 101):
+            a.max_CG_iter, a.CG_tol = m, 1e-8
+            try:
+                _, it, _, _ = a.CG_solver(fn, rhs, x0)
+                assert it == -1
+            except (ValueError, TypeError):
+                kstar = m
+                break
+        assert kstar is not None
+        a.max_CG_iter, a.CG_tol = kstar, 0.0
+        x, it, al, be = a.CG_solver(fn, rhs, x0)
+        assert it == -1 and len(al) == kstar
+        out[f"{nm}_iters"] = kstar
+        out[f"{nm}_x"] = x.numpy()
+        out[f"{nm}_alpha"] = torch.stack(al).numpy()          # (K*, B)
+        out[f"{nm}_beta"] = torch.stack(be).numpy()
+        # per-sample stop of the same systems (what cg_convergence='per_sample' reproduces): B single-sample runs
+        a.max_CG_iter, a.CG_tol = 100, 1e-8
+        out[f"{nm}_iters_per_sample"] = np.asarray([a.CG_solver(fn, rhs[b:b + 1], x0[b:b + 1])[1] for b in range(B)])
+    for key in ("rho", "rho_u", "rho_d", "mu_u", "mu_d1", "mu_d2"):
+        out[key] = getattr(a, key)
+    np.savez_compressed(os.path.join(OUT, "g10_cg_batchmax.npz"), T=T, t_in=t_in, n=n, B=B, **out)
+
+
 def main():
     only = set(sys.argv[1:])
     if only == {"g7"}:
@@ -398,6 +503,14 @@ def main():
         return            # e.g. `gen_golden.py g1` regenerates the table fixtures only
     e12, d12 = make_graph(12, 3, seed=0, lo=1.0, hi=10.0, ring=True)
     e30, d30 = make_graph(30, 8, seed=1, lo=3.0, hi=600.0, ring=False)
+    if only and only <= {"g8", "g9", "g10"}:      # the round-2 groups alone (the older fixtures stay byte-identical)
+        if "g8" in only:
+            g8_ln(12, e12, d12, k=3, sigma=5.0)
+        if "g9" in only:
+            g9_two_loops(30, e30, d30, k=4, sigma=50.0)
+        if "g10" in only:
+            g10_cg_batchmax(12, e12, d12, k=3, sigma=5.0)
+        return
     g1_tables("small", 12, e12, d12, k=3, sigma=5.0)
     g1_tables("pems", 30, e30, d30, k=4, sigma=50.0)
     # integer edge lengths: many equal shortest-path distances, pins networkx's tie order (heap push counter,
@@ -414,6 +527,9 @@ def main():
     g5_batched(30, e30, d30, k=4, sigma=50.0)
     g6_kats()
     g7_dataset()
+    g8_ln(12, e12, d12, k=3, sigma=5.0)
+    g9_two_loops(30, e30, d30, k=4, sigma=50.0)
+    g10_cg_batchmax(12, e12, d12, k=3, sigma=5.0)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,5 +1,6 @@
-"""Multi-rank path on CPU: world_size-2 (and 3) gloo process groups exercise the batch sharding and the
-final gather of mgadmm.dist.sharded_solve.  The per-rank solve is the CPU oracle here (test
+"""Multi-rank path on CPU: world_size-2 (and 3) gloo process groups exercise the batch sharding, the final gather
+of mgadmm.dist.sharded_solve (to one rank, as BASELINE.json's north star names it, or to all) and the re-forming of the
+reference-style whole-batch residual history from the per-shard histories (mgadmm.dist.gather_history).  The per-rank solve is the CPU oracle here (test
 infrastructure; the product path runs the HIP solver on each rank's GPU) -- what is under test is the
 partitioning, the absence of any collective before the gather, and the reassembly order."""
 import os
@@ -22,31 +23,61 @@ def _worker(rank, world, port, B, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from helpers import make_oracle
-    from mgadmm.dist import shard_bounds, sharded_solve
+    from mgadmm.dist import gather_history, shard_bounds, sharded_solve
     meta = load_golden("g4_meta.npz")
     g = load_golden("g5_batched.npz")
     y = torch.from_numpy(g["y"][:B])
     calls = []
+    last = {}
 
     def solve_fn(ys, ms):
         calls.append(ys.shape[0])
         o = make_oracle(meta, "knn")
         o.max_ADMM_iter = 3
+        last["o"] = o
         return torch.from_numpy(o.combined_loop(ys.numpy()))
 
-    x = sharded_solve(solve_fn, y)
+    x = sharded_solve(solve_fn, y, gather="all")
     lo, hi = shard_bounds(B, world, rank)
     assert calls == ([hi - lo] if hi > lo else [])
+    # the per-shard residual history, combined on rank 0: sqrt(sum local^2) / sample-weighted means
+    hist = last["o"].hist if hi > lo else make_oracle(meta, "knn").hist
+    gh = gather_history(hist, hi - lo)
+    assert (gh is not None) == (rank == 0)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "hist.npz"), **{k: np.asarray(v) for k, v in gh.items() if k.endswith("_list")},
+                 iters=np.array(gh["iters_per_shard"]), samples=np.array(gh["samples_per_shard"]))
+    # default: ONE gather to rank 0 -- only rank 0 holds the full tensor
+    xr = sharded_solve(solve_fn, y)
+    assert (xr is not None) == (rank == 0)
+    if rank == 0:
+        assert torch.equal(xr, x)
     xs = sharded_solve(solve_fn, y, gather=False)
     # sub-blocks with asynchronous gathers: same result, one solve call per non-empty sub-block
     calls.clear()
-    xc = sharded_solve(solve_fn, y, chunks=3)
+    xc = sharded_solve(solve_fn, y, gather="all", chunks=3)
     assert torch.equal(xc, x)
     assert sum(calls) == hi - lo and len(calls) == min(3, hi - lo)
+    xc0 = sharded_solve(solve_fn, y, chunks=2, dst=world - 1)
+    assert (xc0 is not None) == (rank == world - 1) and (xc0 is None or torch.equal(xc0, x))
     assert torch.equal(sharded_solve(solve_fn, y, gather=False, chunks=2), xs) if xs is not None else True
     np.save(os.path.join(out_dir, f"x_rank{rank}.npy"), x.numpy())
     if xs is not None:
         np.save(os.path.join(out_dir, f"shard_rank{rank}.npy"), xs.numpy())
+    # early stop is per shard (no collective on the convergence path): with a loose tolerance every shard stops on
+    # ITS OWN norms, i.e. it equals the solve of that block alone; the combined history covers the common iterations
+    def solve_stop(ys, ms):
+        o = make_oracle(meta, "knn")
+        o.max_ADMM_iter, o.ADMM_tol = 40, 60.0
+        last["o"] = o
+        return torch.from_numpy(o.combined_loop(ys.numpy()))
+
+    xe = sharded_solve(solve_stop, y, gather=False)
+    if xe is not None:
+        np.save(os.path.join(out_dir, f"stop_rank{rank}.npy"), xe.numpy())
+    ge = gather_history(last["o"].hist if hi > lo else make_oracle(meta, "knn").hist, hi - lo)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "hist_stop.npz"), iters=np.array(ge["iters_per_shard"]), p=np.asarray(ge["p_res_list"]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,6 +99,27 @@ def test_sharded_solve_gloo(tmp_path, world, B):
         np.testing.assert_allclose(x, ref, rtol=1e-12)          # samples are independent: sharding changes nothing
         lo, hi = shard_bounds(B, world, r)
         np.testing.assert_allclose(np.load(tmp_path / f"shard_rank{r}.npy"), ref[lo:hi], rtol=1e-12)
+    # the combined history equals the history of the unsharded solve (whole-batch Frobenius norms, ADMM.py:612-636)
+    h = np.load(tmp_path / "hist.npz")
+    assert h["iters"].tolist() == [3] * world and int(h["samples"].sum()) == B
+    np.testing.assert_allclose(h["p_res_list"], np.array(o.hist.p_res_list), rtol=1e-10)
+    np.testing.assert_allclose(h["d_res_list"], np.array(o.hist.d_res_list), rtol=1e-10)
+    np.testing.assert_allclose(h["x_shift_list"][:, 0], np.array(o.hist.x_shift_list), rtol=1e-10)
+    np.testing.assert_allclose(h["recover_list"][:, 0], np.array(o.hist.recover_list), rtol=1e-10)
+    for k in ("GLR_list", "DGTV_list", "DGLR_list"):
+        np.testing.assert_allclose(h[k][:, 0], np.array(getattr(o.hist, k)), rtol=1e-10)
+    # early stop enabled: every shard equals the stand-alone solve of its block; iteration counts may differ per shard
+    hs = np.load(tmp_path / "hist_stop.npz")
+    for r in range(world):
+        lo, hi = shard_bounds(B, world, r)
+        oo = make_oracle(meta, "knn")
+        oo.max_ADMM_iter, oo.ADMM_tol = 40, 60.0
+        alone = oo.combined_loop(g["y"][lo:hi])
+        np.testing.assert_allclose(np.load(tmp_path / f"stop_rank{r}.npy"), alone, rtol=1e-12)
+        assert hs["iters"][r] == len(oo.hist.p_res_list)
+    assert hs["p"].shape[0] == hs["iters"].min()
+    if (world, B) == (2, 8):
+        assert len(set(hs["iters"].tolist())) > 1 and hs["iters"].max() < 40      # shards really stop at different iterations
 
 
 def test_sharded_solve_without_process_group():

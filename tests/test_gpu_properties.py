@@ -77,6 +77,26 @@ def test_cfg3_tiled_and_plain_kernels_agree(cfg3, monkeypatch):
     plain.close()
 
 
+def test_cfg3_fused_cldr_kernel_equals_two_pass_form(cfg3, monkeypatch):
+    """k_cldr (Ldr^T Ldr in one pass, q = Ldr x recomputed on the tile halo) against Ldr followed by Ldr^T through HBM:
+    same sums in the same entry order (only the 0.2 % overflow entries of the two-pass tiles are added in another order),
+    so the operator values agree to the last bits and CG takes the same path."""
+    blk, n, B = cfg3
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, 24, n, 1, device="cuda", generator=g)
+    monkeypatch.setenv("MGADMM_FUSED", "0")
+    two, _, _ = _solver("cfg3", bug_compat=False)
+    for nm in ("apply_op_cLdr", "LHS_x", "LHS_zd"):
+        a, b = getattr(blk, nm)(x), getattr(two, nm)(x)
+        assert rel(a, b) < 1e-7, nm
+    rhs = torch.randn(32, 24, n, 1, device="cuda", generator=g)
+    for fn_a, fn_b in ((blk.LHS_x, two.LHS_x), (blk.LHS_zd, two.LHS_zd)):
+        xa, ia, _, _ = blk.CG_solver(fn_a, rhs)
+        xb, ib, _, _ = two.CG_solver(fn_b, rhs)
+        assert torch.equal(ia, ib) and rel(xa, xb) < 1e-6
+    two.close()
+
+
 def test_cfg3_cg_solves_the_system_per_sample(cfg3):
     """After CG_solver, A x = b holds to the recursive-residual tolerance and every sample reports its own count."""
     blk, n, B = cfg3

@@ -279,3 +279,60 @@ def test_g5_batched_equals_looped():
     np.testing.assert_allclose(np.array(o.hist.p_res_list), pr, rtol=1e-8)
     np.testing.assert_allclose(o.hist.GLR_list, g["GLR"].mean(0), rtol=1e-9)
     assert rel(o.state["phi"], g["phi"].reshape(o.state["phi"].shape)) < 1e-10
+
+
+# ------------------------------------------------------------------ round-2 fixture groups (g8, g9, g10)
+def _oracle_from(g, prefix, mode, **kw):
+    info = {k: float(g[k]) for k in ("rho", "rho_u", "rho_d", "mu_u", "mu_d1", "mu_d2")} if "rho" in g.files else \
+        dict(rho=1.0, rho_u=1.0, rho_d=1.0, mu_u=1.0, mu_d1=1.0, mu_d2=1.0)
+    cl = g[prefix + "cl"]
+    d_ew = g[prefix + "d_ew"] if (prefix + "d_ew") in g.files else None
+    return orc.OracleADMM(cl, g[prefix + "u_ew"], d_ew, info, mode=mode, T=int(g["T"]), t_in=int(g["t_in"]), **kw)
+
+
+@pytest.mark.parametrize("mode", ["knn", "physical", "line"])
+def test_apply_op_Ln_matches_reference(mode):
+    """g8: apply_op_Ln (ADMM.py:248-288) as a dense matrix and on a multi-channel random tensor."""
+    g = load_golden("g8_ln.npz")
+    o = _oracle_from(g, mode + "_", mode)
+    assert rel(o.dense(o.apply_op_Ln), g[mode + "_Ln"]) < 1e-15
+    x = g[mode + "_x"]
+    got = np.stack([o.apply_op_Ln(x[..., c:c + 1]) for c in range(x.shape[-1])], -1)[..., 0, :]
+    assert rel(got, g[mode + "_y"]) < 1e-15
+
+
+@pytest.mark.parametrize("mode,abl", [("knn", "None"), ("knn", "DGLR"), ("knn", "DGTV"), ("line", "None"), ("line", "DGLR"), ("line", "DGTV")])
+def test_two_loops_matches_reference(mode, abl):
+    """g9: two_loops (ADMM.py:410-508), 3 outer x 4 inner iterations: x / gamma / phi at every outer iteration as the
+    reference hands them to phi_direct, and every CG iteration count."""
+    g = load_golden("g9_two_loops.npz")
+    info = {k: float(g[k]) for k in ("rho", "rho_u", "rho_d", "mu_u", "mu_d1", "mu_d2")}
+    o = orc.OracleADMM(g["cl"], g["u_ew"], g["d_ew"] if mode == "knn" else None, info, mode=mode, ablation=abl,
+                       T=int(g["T"]), t_in=int(g["t_in"]))
+    o.max_ADMM_iter, o.max_inner_iter = int(g["max_outer"]), int(g["max_inner"])
+    o.two_loops(g["y"])
+    tag = f"{mode}_{abl}"
+    if abl != "DGTV":
+        for kq in ("x", "gamma", "phi"):
+            got = np.stack([r[kq] for r in o.outer])
+            assert rel(got, g[f"{tag}_{kq}"]) < 1e-11, kq
+    assert np.array_equal(np.array(o.hist.CG_iter_x).reshape(-1), g[f"{tag}_cg_x"])
+    assert np.array_equal(np.array(o.hist.CG_iter_zu).reshape(-1), g[f"{tag}_cg_zu"])
+    if abl != "DGLR":
+        assert np.array_equal(np.array(o.hist.CG_iter_zd).reshape(-1), g[f"{tag}_cg_zd"])
+
+
+@pytest.mark.parametrize("nm", ["x", "zu", "zd"])
+def test_cg_batch_max_stop_matches_reference(nm):
+    """g10: the reference's batch-global CG stop (ADMM.py:360) on 8 samples that converge at different iterations."""
+    g = load_golden("g10_cg_batchmax.npz")
+    o = _oracle_from(g, "", "knn", cg_convergence="batch_max")
+    fn = {"x": o.LHS_x, "zu": o.LHS_zu, "zd": o.LHS_zd}[nm]
+    x, it, al, be = o.CG_solver(fn, g["rhs"], g["x0"])
+    assert (it == int(g[nm + "_iters"])).all()
+    assert rel(x, g[nm + "_x"]) < 1e-12
+    np.testing.assert_allclose(al, g[nm + "_alpha"], rtol=1e-9)
+    np.testing.assert_allclose(be, g[nm + "_beta"], rtol=1e-9)
+    o2 = _oracle_from(g, "", "knn")
+    _, it2, _, _ = o2.CG_solver(fn, g["rhs"], g["x0"])
+    assert np.array_equal(it2, g[nm + "_iters_per_sample"])
