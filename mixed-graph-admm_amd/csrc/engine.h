@@ -252,19 +252,18 @@ struct Engine : EngineBase {
     // ---------------------------------------------------------------- fused cLdr kernel (k_cldr)
     // Tile geometries (VECT columns per lane, NW waves, rows per wave of the tile / of C1 / of C2).  LDS per workgroup =
     // NW * (MQ + MP) * 64 * VECT * sizeof(S).  MGADMM_CLDR_GEOM selects one (experiments); default per scalar type below.
-    template <int VECT_, int NW_, int MA_, int MQ_, int MP_>
-    struct ClG { static constexpr int VECT = VECT_, NW = NW_, MA = MA_, MQ = MQ_, MP = MP_; };
-    typedef ClG<4, 8, 2, 4, 5> ClG0;     // 16 / 32 / 40 rows of 256 columns: 72 KiB (float), two workgroups per CU
-    typedef ClG<2, 8, 4, 8, 10> ClG1;    // 32 / 64 / 80 rows of 128 columns: 72 KiB (float)
-    typedef ClG<1, 8, 8, 11, 15> ClG2;   // 64 / 88 / 120 rows of 64 columns: 52 KiB (float), three workgroups per CU
-    typedef ClG<4, 16, 2, 3, 5> ClG3;    // 32 / 48 / 80 rows of 256 columns, 16 waves: 128 KiB (float), one workgroup per CU
-    static constexpr int CL_GD = 8, CL_GT = 12;
+    template <int VECT_, int NW_, int MA_, int MQ_, int MP_, int MINW_>
+    struct ClG { static constexpr int VECT = VECT_, NW = NW_, MA = MA_, MQ = MQ_, MP = MP_, MINW = MINW_; };
+    typedef ClG<4, 8, 2, 4, 6, 4> ClG0;     // 16 / 32 / 48 rows of 256 columns: 80 KiB (float), two workgroups fill the 160 KiB LDS exactly
+    typedef ClG<4, 8, 2, 4, 5, 4> ClG1;     // 16 / 32 / 40 rows of 256 columns: 72 KiB (float), two workgroups per CU
+    typedef ClG<1, 8, 8, 11, 15, sizeof(S) == 4 ? 6 : 2> ClG2;   // 64 / 88 / 120 rows of 64 columns: 52 KiB (float) / 104 KiB (double)
+    static constexpr int CL_GT = 12;        // W_d^T slots per row; W_d slots: 6 (no test at all) when no row is longer, else 8
+    int cl_gd = 8;
     int cl_geom = sizeof(S) == 4 ? 0 : 2;   // float64: the narrow geometry (104 KiB)
     void cl_dims(int& vect, int& nw, int& ma, int& mq, int& mp) const {
         switch (cl_geom) {
             case 0: vect = ClG0::VECT; nw = ClG0::NW; ma = ClG0::MA; mq = ClG0::MQ; mp = ClG0::MP; break;
             case 1: vect = ClG1::VECT; nw = ClG1::NW; ma = ClG1::MA; mq = ClG1::MQ; mp = ClG1::MP; break;
-            case 3: vect = ClG3::VECT; nw = ClG3::NW; ma = ClG3::MA; mq = ClG3::MQ; mp = ClG3::MP; break;
             default: vect = ClG2::VECT; nw = ClG2::NW; ma = ClG2::MA; mq = ClG2::MQ; mp = ClG2::MP; break;
         }
     }
@@ -275,14 +274,17 @@ struct Engine : EngineBase {
     }
     void cldr_prepare() {
         cldr_dev.state = -1;
-        if (const char* e = getenv("MGADMM_CLDR_GEOM")) { const int v = atoi(e); if (v >= 0 && v <= 3) cl_geom = v; }
+        if (const char* e = getenv("MGADMM_CLDR_GEOM")) { const int v = atoi(e); if (v >= 0 && v <= 2) cl_geom = v; }
         int vect, nw, ma, mq, mp;
         cl_dims(vect, nw, ma, mq, mp);
         if ((size_t)nw * (mq + mp) * 64 * vect * sizeof(S) > 150 * 1024) { cl_geom = 2; cl_dims(vect, nw, ma, mq, mp); }
         HostCsr A, At;
         if (g->has_perm) { mg_permute_csr(g->hWd, g->perm, g->iperm, A); mg_permute_csr(g->hWdT, g->perm, g->iperm, At); }
         else { A = g->hWd; At = g->hWdT; }
-        CldrCaps caps{nw * ma, nw * mq, nw * mp, CL_GD, CL_GT};
+        cl_gd = 6;
+        for (int i = 0; i < N; ++i)
+            if (A.rowptr[i + 1] - A.rowptr[i] > 6) cl_gd = 8;
+        CldrCaps caps{nw * ma, nw * mq, nw * mp, cl_gd, CL_GT};
         CldrTiles tl;
         if (!build_cldr_tiles(A, At, g->cluster_starts, caps, tl)) return;
         if (getenv("MGADMM_TILE_STATS"))
@@ -330,10 +332,14 @@ struct Engine : EngineBase {
     }
     template <class G, template <typename, int> class E, class... A>
     int rows_cldr_g(const Geom& q, const S* in, const int* live, A... a) {
+        return cl_gd == 6 ? rows_cldr_gd<G, 6, E>(q, in, live, a...) : rows_cldr_gd<G, 8, E>(q, in, live, a...);
+    }
+    template <class G, int GD, template <typename, int> class E, class... A>
+    int rows_cldr_gd(const Geom& q, const S* in, const int* live, A... a) {
         const CldrGeom cg = make_cldr_geom(q);
         CldrMeta mm{cldr_dev.n0, cldr_dev.nC, cldr_dev.rows, cldr_dev.dcol, cldr_dev.dw, cldr_dev.dcnt, cldr_dev.tcol, cldr_dev.tw, cldr_dev.tcnt};
         typedef E<S, G::VECT> Epi;
-        auto fn = k_cldr<S, G::VECT, Epi, G::NW, G::MA, G::MQ, G::MP, CL_GD, CL_GT>;
+        auto fn = k_cldr<S, G::VECT, Epi, G::NW, G::MA, G::MQ, G::MP, GD, CL_GT, G::MINW>;
         MG_TRY(allow_dynamic_lds((const void*)fn, 150 * 1024));
         hipLaunchKernelGGL(fn, dim3(cg.grid), dim3(G::NW * 64), cg.lds_bytes, st, cg, mm, in, Epi{a...}, partials, live);
         cur_P = cg.P;
@@ -349,7 +355,6 @@ struct Engine : EngineBase {
             switch (cl_geom) {
                 case 0: rc = rows_cldr_g<ClG0, E>(q, in, live, a...); break;
                 case 1: rc = rows_cldr_g<ClG1, E>(q, in, live, a...); break;
-                case 3: rc = rows_cldr_g<ClG3, E>(q, in, live, a...); break;
                 default: rc = rows_cldr_g<ClG2, E>(q, in, live, a...); break;
             }
         } else {

@@ -421,10 +421,23 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     const int ty = a.mask ? a.T : a.t_in;
     const float* yb = a.y + (size_t)b * ty * a.N;
 
-    float x[TPG];
+    // Global operands are requested in BATCHES ahead of the barriers that separate their uses (the compiler does not move
+    // loads across a barrier): one exposed HBM latency per phase boundary instead of one per operand group.
+    // ---- batch 1: x_old and every operand of RHS_x (ADMM.py:556-564)
+    float x[TPG], o[TPG], v[TPG];
 #pragma unroll
-    for (int k = 0; k < TPG; ++k) x[k] = c.active ? xo[c.gl(k)] : 0.f;
-
+    for (int k = 0; k < TPG; ++k) {
+        x[k] = o[k] = v[k] = 0.f;
+        if (c.active) {
+            const int e = c.gl(k);
+            const int t = c.t0 + k;
+            x[k] = xo[e];
+            const float yv = (t < ty) ? yb[t * a.N + c.i] : 0.f;
+            if (a.has_zd) o[k] = (a.rho_u * zu[e] + a.rho_d * zd[e]) / 2.f - (gu[e] + gd[e]) / 2.f + yv;
+            else o[k] = a.rho_u * zu[e] / 2.f - gu[e] / 2.f + yv;
+            if (a.has_phi && !a.first) v[k] = gam[e] + a.rho * phi[e];
+        }
+    }
     // ---- first iteration only: phi = Ldr x0 (ADMM.py:541); the dual variables were filled by k_init_lds
     if (a.has_phi && a.first) {
         float ph[TPG];
@@ -434,37 +447,25 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         __syncthreads();
         if (c.active) c.op_ldr(P, x, ph);
         c.putg(phi, ph);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) v[k] = c.active ? gam[c.gl(k)] + a.rho * ph[k] : 0.f;
         __syncthreads();
     }
 
-    // ---- RHS_x (ADMM.py:556-564)
+    // ---- RHS_x
     float rhs[TPG];
     {
         float l[TPG];
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = 0.f;
         if (a.has_phi) {
-            float v[TPG];
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) v[k] = c.active ? gam[c.gl(k)] + a.rho * phi[c.gl(k)] : 0.f;
             c.put(P, v);
             __syncthreads();
             if (c.active) c.op_ldrt(P, v, l);
             __syncthreads();
         }
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) {
-            rhs[k] = 0.f;
-            if (c.active) {
-                const int e = c.gl(k);
-                const int t = c.t0 + k;
-                const float yv = (t < ty) ? yb[t * a.N + c.i] : 0.f;
-                float o;
-                if (a.has_zd) o = (a.rho_u * zu[e] + a.rho_d * zd[e]) / 2.f - (gu[e] + gd[e]) / 2.f + yv;
-                else o = a.rho_u * zu[e] / 2.f - gu[e] / 2.f + yv;
-                rhs[k] = a.has_phi ? l[k] / 2.f + o : o;
-            }
-        }
+        for (int k = 0; k < TPG; ++k) rhs[k] = c.active ? (a.has_phi ? l[k] / 2.f + o[k] : o[k]) : 0.f;
     }
     float* ah = a.record ? a.alpha_hist + b : nullptr;
     float* bh = a.record ? a.beta_hist + b : nullptr;
@@ -476,51 +477,74 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     else itx = lds_cg<TPG, BAND, 0, SB>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, 0.f, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
     c.putg(xn, x);
 
+    // ---- batch 2: operands of the x metrics and of the zu solve
+    float z[TPG], gq[TPG];
     {
+        float xold[TPG], yv[TPG], mv[TPG];
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            xold[k] = yv[k] = mv[k] = z[k] = gq[k] = 0.f;
+            if (c.active) {
+                const int e = c.gl(k);
+                const int t = c.t0 + k;
+                xold[k] = xo[e];
+                if (mk) { mv[k] = mk[e]; yv[k] = yb[t * a.N + c.i]; }
+                else if (t < a.t_in) yv[k] = yb[t * a.N + c.i];
+                z[k] = zu[e];
+                gq[k] = gu[e];
+            }
+        }
         double m_xshift = 0, m_rec = 0;
         if (c.active) {
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
                 const int t = c.t0 + k;
-                const double dx = (double)x[k] - (double)xo[c.gl(k)];
+                const double dx = (double)x[k] - (double)xold[k];
                 m_xshift += dx * dx;
                 if (mk) {
-                    const double e = (double)(x[k] * mk[c.gl(k)] - yb[t * a.N + c.i]);
+                    const double e = (double)(x[k] * mv[k] - yv[k]);
                     m_rec += e * e;
                 } else if (t < a.t_in) {
-                    const double e = (double)(x[k] - yb[t * a.N + c.i]);
+                    const double e = (double)(x[k] - yv[k]);
                     m_rec += e * e;
                 }
             }
         }
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) rhs[k] = c.active ? gq[k] / 2.f + a.rho_u / 2.f * x[k] : 0.f;     // x = the x_new just stored
         emit(MGADMM_M_XSHIFT, m_xshift, true);
         emit(MGADMM_M_RECOVER, m_rec, true);
     }
 
     // ---- zu solve + gamma_u update (ADMM.py:579-580, 595)
-    int itzu;
+    int itzu = lds_cg<TPG, BAND, 2, SB>(c, br, z, rhs, nullptr, 0, 0, a.rho_u / 2.f, a.mu_u, a.max_cg, a.cg_tol, ah ? ah + hstride : nullptr,
+                                        bh ? bh + hstride : nullptr, a.Bp, a.nonfinite);
+    // ---- batch 3: x_new, old zu, gamma_u for the update + the operands of the next phase (zd solve, or the phi prox)
+    float xr[TPG], zn[TPG], gn[TPG];
     {
-        float z[TPG];
+        float zo[TPG], gv[TPG];
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
-            z[k] = 0.f;
+            xr[k] = zn[k] = gn[k] = zo[k] = gv[k] = 0.f;
             if (c.active) {
-                z[k] = zu[c.gl(k)];
-                rhs[k] = gu[c.gl(k)] / 2.f + a.rho_u / 2.f * xn[c.gl(k)];
+                const int e = c.gl(k);
+                xr[k] = xn[e];
+                zo[k] = zu[e];
+                gv[k] = gu[e];
+                if (a.has_zd) { zn[k] = zd[e]; gn[k] = gd[e]; }
+                else if (a.has_phi) { zn[k] = phi[e]; gn[k] = gam[e]; }
             }
         }
-        itzu = lds_cg<TPG, BAND, 2, SB>(c, br, z, rhs, nullptr, 0, 0, a.rho_u / 2.f, a.mu_u, a.max_cg, a.cg_tol, ah ? ah + hstride : nullptr,
-                              bh ? bh + hstride : nullptr, a.Bp, a.nonfinite);
         double m_prizu = 0, m_dualzu = 0;
         if (c.active) {
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
                 const int e = c.gl(k);
-                const float pz = xn[e] - z[k], dz = z[k] - zu[e];
+                const float pz = xr[k] - z[k], dz = z[k] - zo[k];
                 m_prizu += (double)pz * pz;
                 m_dualzu += (double)dz * dz;
                 zu[e] = z[k];
-                gu[e] = gu[e] + a.rho_u * pz;
+                gu[e] = gv[k] + a.rho_u * pz;
             }
         }
         emit(MGADMM_M_PRI_ZU, m_prizu, true);
@@ -529,27 +553,36 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     // ---- zd solve + gamma_d update (ADMM.py:586-588, 597)
     int itzd = 0;
     if (a.has_zd) {
-        float z[TPG];
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
-            z[k] = 0.f;
-            if (c.active) {
-                z[k] = zd[c.gl(k)];
-                rhs[k] = gd[c.gl(k)] / 2.f + a.rho_d / 2.f * xn[c.gl(k)];
-            }
+            z[k] = zn[k];
+            rhs[k] = c.active ? gn[k] / 2.f + a.rho_d / 2.f * xr[k] : 0.f;
         }
         itzd = lds_cg<TPG, BAND, 1, SB>(c, br, z, rhs, nullptr, 0, 0, a.rho_d / 2.f, a.mu_d2, a.max_cg, a.cg_tol,
                               ah ? ah + 2 * hstride : nullptr, bh ? bh + 2 * hstride : nullptr, a.Bp, a.nonfinite);
+        // ---- batch 4: x_new, old zd, gamma_d + the operands of the phi prox
+        float zo[TPG], gv[TPG];
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            xr[k] = zo[k] = gv[k] = zn[k] = gn[k] = 0.f;
+            if (c.active) {
+                const int e = c.gl(k);
+                xr[k] = xn[e];
+                zo[k] = zd[e];
+                gv[k] = gd[e];
+                if (a.has_phi) { zn[k] = phi[e]; gn[k] = gam[e]; }
+            }
+        }
         double m_prizd = 0, m_dualzd = 0;
         if (c.active) {
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
                 const int e = c.gl(k);
-                const float pz = xn[e] - z[k], dz = z[k] - zd[e];
+                const float pz = xr[k] - z[k], dz = z[k] - zo[k];
                 m_prizd += (double)pz * pz;
                 m_dualzd += (double)dz * dz;
                 zd[e] = z[k];
-                gd[e] = gd[e] + a.rho_d * pz;
+                gd[e] = gv[k] + a.rho_d * pz;
             }
         }
         emit(MGADMM_M_PRI_ZD, m_prizd, true);
@@ -559,17 +592,14 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         emit(MGADMM_M_DUAL_ZD, 0.0, false);
     }
 
-    // ---- phi prox, gamma update, Ldr/Lu based diagnostics (ADMM.py:600-606, 619, 627-637)
+    // ---- phi prox, gamma update, Ldr/Lu based diagnostics (ADMM.py:600-606, 619, 627-637); xr = x_new, zn = phi_old, gn = gamma
     double m_priphi = 0, m_dualphi = 0, m_dgtv = 0, m_dglr = 0, m_glr = 0;
     __syncthreads();          // every LDS read of the last CG is done
-    float xv[TPG];
-#pragma unroll
-    for (int k = 0; k < TPG; ++k) xv[k] = c.active ? xn[c.gl(k)] : 0.f;
-    c.put(P, xv);
+    c.put(P, xr);
     __syncthreads();
     if (c.active) {
         float l[TPG];
-        c.op_ldr(P, xv, l);
+        c.op_ldr(P, xr, l);
         const float thr = a.mu_d1 / a.rho;
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
@@ -577,20 +607,20 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
             m_dglr += (double)l[k] * l[k];
             if (a.has_phi) {
                 const int e = c.gl(k);
-                const float gv = gam[e];
+                const float gv = gn[k];
                 const float s = l[k] - gv / a.rho;
                 const float u = fabsf(s) - thr;
                 const float pn = (u > 0.f) ? (s > 0.f ? u : -u) : 0.f;
-                const float dd = pn - l[k], dp = pn - phi[e];
+                const float dd = pn - l[k], dp = pn - zn[k];
                 m_priphi += (double)dd * dd;
                 m_dualphi += (double)dp * dp;
                 phi[e] = pn;
                 gam[e] = gv + a.rho * dd;
             }
         }
-        c.op_lu(P, xv, l);
+        c.op_lu(P, xr, l);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) m_glr += (double)xv[k] * (double)l[k];
+        for (int k = 0; k < TPG; ++k) m_glr += (double)xr[k] * (double)l[k];
     }
 
     emit(MGADMM_M_PRI_PHI, m_priphi, a.has_phi);

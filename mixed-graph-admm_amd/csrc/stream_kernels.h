@@ -547,17 +547,20 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
 // 64*VECT-column chunk and sweeps t = 0 .. T-1.  For the step t it holds in LDS
 //     P = x_t      on C2 = C1 u {W_d neighbours of C1}      (2-hop set, <= NW*MP rows)
 //     Q = q_{t+1}  on C1 = tile u {W_d^T neighbours of it}  (1-hop set, <= NW*MQ rows), q = Ldr x recomputed on the halo
-// and in registers x_{t+1} of its C2 rows (requested one step ahead), x_t and q_t of its own rows:
+// and in registers x_{t+1} and x_{t+2} of its C2 rows (requested two steps ahead), x_t and q_t of its own rows:
 //     phase A   q_{t+1}[j] = x_{t+1}[j] - sum_e W_d[j,e] P[col_e]            for its rows j of C1   -> Q
 //     barrier
-//     phase C   P <- x_{t+1};  request x_{t+2};
-//               l_t[i] = [t>0 or q1] q_t[i] - sum_e W_d^T[i,e] Q[col_e]      for its own rows i     -> epilogue
+//     phase C   l_t[i] = [t>0 or q1] q_t[i] - sum_e W_d^T[i,e] Q[col_e]      for its own rows i     -> epilogue
+//               P <- x_{t+1};  request x_{t+3}
 //     barrier
 // Local row l of a tile belongs to wave l % NW for all three roles, so the self terms are already in that wave's
 // registers.  Per-row (local column, weight) slots live in VGPR lanes and are broadcast with v_readlane exactly like
 // in k_tile (tables built on the host by build_cldr_tiles, cldr_tiles.h, which has a CPU replay test).  Sums run in
 // CSR entry order and q is rounded to S like the stored q of the two-pass form: the result is BITWISE the same.
 // ---------------------------------------------------------------------------------------------
+#ifndef CLDR_PREFETCH
+#define CLDR_PREFETCH 1      // time steps the rows of x are requested ahead of their use (1 or 2; measured: 2 costs 24 VGPRs and is 5 % slower)
+#endif
 struct CldrGeom {
     int T, N, B, Bp;
     int CH;           // column chunks of 64*VECT
@@ -582,33 +585,48 @@ struct CldrMeta {
     const int* tcnt;   // [NT][Rcap]
 };
 
-// sum_e w_e * IMG[col_e] for one row whose slots sit in lanes [slot0, slot0 + G) of the metadata registers;
-// pairs of slots past the first are skipped when the row has no entry there (wave-uniform)
-template <typename S, int VECT, int G, int K>
+// sum_e w_e * IMG[col_e] for one row whose slots sit in lanes [slot0, slot0 + G) of the metadata registers.  The first
+// GFIX slots are read unconditionally and TOGETHER (pad slots carry weight 0): one LDS round trip for a typical row and
+// no branch, so the scheduler can overlap the rows of a phase; pairs of slots past GFIX are skipped when the row has
+// no entry there (wave-uniform).  The sum runs in slot (= CSR entry) order.
+template <typename S, int VECT, int GFIX, int G, int K>
 __device__ __forceinline__ Vec<S, VECT> cldr_gather(const S* __restrict__ img_lane, const int (&mc)[K], const int (&mw)[K], int slot0, int cnt) {
     Vec<S, VECT> sum;
 #pragma unroll
     for (int v = 0; v < VECT; ++v) sum.v[v] = S(0);
+    {
+        Vec<S, VECT> nv[GFIX];
 #pragma unroll
-    for (int u0 = 0; u0 < G; u0 += 2) {
-        if (u0 == 0 || cnt > u0) {
-            constexpr int GB = 2;
-            Vec<S, VECT> nv[GB];
+        for (int u = 0; u < GFIX; ++u) {
+            const int s = slot0 + u;
+            nv[u] = ldv<S, VECT>(img_lane + __builtin_amdgcn_readlane(mc[s >> 6], s & 63));
+        }
 #pragma unroll
-            for (int u = 0; u < GB; ++u) {
+        for (int u = 0; u < GFIX; ++u) {
+            const int s = slot0 + u;
+            const S w = (S)__int_as_float(__builtin_amdgcn_readlane(mw[s >> 6], s & 63));
+#pragma unroll
+            for (int v = 0; v < VECT; ++v) sum.v[v] = fma(w, nv[u].v[v], sum.v[v]);   // explicit: one rounding, like k_tile
+        }
+    }
+#pragma unroll
+    for (int u0 = GFIX; u0 < G; u0 += 2) {
+        if (cnt > u0) {
+            Vec<S, VECT> nv[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
                 if (u0 + u < G) {
                     const int s = slot0 + u0 + u;
-                    const int lc = __builtin_amdgcn_readlane(mc[s >> 6], s & 63);
-                    nv[u] = ldv<S, VECT>(img_lane + lc);
+                    nv[u] = ldv<S, VECT>(img_lane + __builtin_amdgcn_readlane(mc[s >> 6], s & 63));
                 }
             }
 #pragma unroll
-            for (int u = 0; u < GB; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 if (u0 + u < G) {
                     const int s = slot0 + u0 + u;
                     const S w = (S)__int_as_float(__builtin_amdgcn_readlane(mw[s >> 6], s & 63));
 #pragma unroll
-                    for (int v = 0; v < VECT; ++v) sum.v[v] = fma(w, nv[u].v[v], sum.v[v]);   // explicit: one rounding, like k_tile
+                    for (int v = 0; v < VECT; ++v) sum.v[v] = fma(w, nv[u].v[v], sum.v[v]);
                 }
             }
         }
@@ -616,8 +634,9 @@ __device__ __forceinline__ Vec<S, VECT> cldr_gather(const S* __restrict__ img_la
     return sum;
 }
 
-template <typename S, int VECT, class Epi, int NW, int MA, int MQ, int MP, int GD, int GT>
-__global__ __launch_bounds__(NW * 64) void k_cldr(CldrGeom g, CldrMeta m, const S* __restrict__ in, Epi epi_in,
+// MINW: waves per SIMD the register allocation must leave room for (= resident workgroups per CU * NW / 4)
+template <typename S, int VECT, class Epi, int NW, int MA, int MQ, int MP, int GD, int GT, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, const S* __restrict__ in, Epi epi_in,
                                                   S* __restrict__ partials, const int* __restrict__ live) {
     static_assert(MA <= MQ && MQ <= MP && MP <= 64, "own rows are a prefix of C1, C1 a prefix of C2");
     extern __shared__ __align__(16) unsigned char cldr_raw[];
@@ -625,6 +644,7 @@ __global__ __launch_bounds__(NW * 64) void k_cldr(CldrGeom g, CldrMeta m, const 
     constexpr int W = 64 * VECT;
     constexpr int RCAP = NW * MA, C1CAP = NW * MQ, C2CAP = NW * MP;
     constexpr int KD = (MQ * GD + 63) / 64, KT = (MA * GT + 63) / 64;
+    constexpr int GDF = GD < 6 ? GD : 6, GTF = GT < 6 ? GT : 6;   // slots gathered without a test (k + 1 = 5 entries per W_d row; 78 % of the W_d^T rows have <= 6)
     S* Pimg = reinterpret_cast<S*>(cldr_raw);          // [C2CAP][W]
     S* Qimg = Pimg + (size_t)C2CAP * W;                // [C1CAP][W]
     const int lane = threadIdx.x & 63;
@@ -685,43 +705,54 @@ __global__ __launch_bounds__(NW * 64) void k_cldr(CldrGeom g, CldrMeta m, const 
         const S* pl = Pimg + lane * VECT;
         const S* ql = Qimg + lane * VECT;
         const size_t slice = (size_t)g.N * g.Bp;
-        Vec<S, VECT> pn[MP];            // x_{t+1} of this wave's rows of C2 (requested one step ahead)
+        Vec<S, VECT> pnA[MP], pnB[MP];  // x_{t+1} / x_{t+2} of this wave's rows of C2: requested TWO steps ahead, the buffers alternate
         Vec<S, VECT> pc[MA], qp[MA];    // x_t and q_t of its own rows
-        // prologue: x_0 -> P image, q_0 = 0, request x_1
+#pragma unroll
+        for (int k = 0; k < MP; ++k)
+#pragma unroll
+            for (int v = 0; v < VECT; ++v) pnA[k].v[v] = pnB[k].v[v] = S(0);   // row slots past |C2| are never loaded
+        // prologue: x_0 -> P image, q_0 = 0, request x_1 and x_2
 #pragma unroll
         for (int k = 0; k < MP; ++k) {
             const int hr = __builtin_amdgcn_readlane(hrow, k);
-            if (hr >= 0) pn[k] = ldv<S, VECT>(in + (size_t)hr * g.Bp + col0);
+            if (hr >= 0) pnA[k] = ldv<S, VECT>(in + (size_t)hr * g.Bp + col0);
         }
 #pragma unroll
         for (int k = 0; k < MP; ++k) {
             const int hr = __builtin_amdgcn_readlane(hrow, k);
-            if (hr >= 0) stl<S, VECT>(Pimg + (size_t)(wave + NW * k) * W + lane * VECT, pn[k]);
+            if (hr >= 0) stl<S, VECT>(Pimg + (size_t)(wave + NW * k) * W + lane * VECT, pnA[k]);
         }
 #pragma unroll
         for (int k = 0; k < MA; ++k) {
-            pc[k] = pn[k];
+            pc[k] = pnA[k];
 #pragma unroll
             for (int v = 0; v < VECT; ++v) qp[k].v[v] = S(0);
         }
-        if (g.T > 1) {
+        auto request = [&](Vec<S, VECT> (&pn)[MP], int tt) {
+            if (tt < g.T) {
+                const S* nb = in + (size_t)tt * slice + col0;
 #pragma unroll
-            for (int k = 0; k < MP; ++k) {
-                const int hr = __builtin_amdgcn_readlane(hrow, k);
-                if (hr >= 0) pn[k] = ldv<S, VECT>(in + slice + (size_t)hr * g.Bp + col0);
+                for (int k = 0; k < MP; ++k) {
+                    const int hr = __builtin_amdgcn_readlane(hrow, k);
+                    if (hr >= 0) pn[k] = ldv<S, VECT>(nb + (size_t)hr * g.Bp);
+                }
             }
-        }
+        };
+        request(pnA, 1);
+        if (CLDR_PREFETCH == 2) request(pnB, 2);
         __syncthreads();
-        for (int t = 0; t < g.T; ++t) {
+        // one time step; pn holds x_{t+1} on entry and is re-requested with x_{t+3} as soon as it has been consumed
+        auto step = [&](int t, Vec<S, VECT> (&pn)[MP]) {
             const bool nxt = t + 1 < g.T;
             Vec<S, VECT> qn[MA];
             // ---- phase A: q_{t+1} on this wave's rows of C1
             if (nxt) {
+                // one LDS round trip per row (the first GDF slots are read together); row slots past |C1| are skipped
 #pragma unroll
                 for (int k = 0; k < MQ; ++k) {
                     const int l = wave + NW * k;
                     if (l < nC1) {
-                        const Vec<S, VECT> sum = cldr_gather<S, VECT, GD, KD>(pl, mdc, mdw, k * GD, __builtin_amdgcn_readlane(dcn, k));
+                        const Vec<S, VECT> sum = cldr_gather<S, VECT, GDF, GD, KD>(pl, mdc, mdw, k * GD, __builtin_amdgcn_readlane(dcn, k));
                         Vec<S, VECT> qv;
 #pragma unroll
                         for (int v = 0; v < VECT; ++v) qv.v[v] = S(1) * pn[k].v[v] - sum.v[v];
@@ -731,8 +762,23 @@ __global__ __launch_bounds__(NW * 64) void k_cldr(CldrGeom g, CldrMeta m, const 
                 }
             }
             __syncthreads();                              // Q complete; every gather from P is done
-            // ---- phase C: P <- x_{t+1}, request x_{t+2}, own rows of l_t through the epilogue
-            Vec<S, VECT> pcn[MA];
+            // ---- phase C: own rows of l_t through the epilogue, then P <- x_{t+1} and the request of x_{t+3}
+            const S selfc = (t > 0 || g.q1) ? S(1) : S(0);
+            Vec<S, VECT> lv[MA];
+#pragma unroll
+            for (int k = 0; k < MA; ++k) {
+                Vec<S, VECT> sum;
+#pragma unroll
+                for (int v = 0; v < VECT; ++v) sum.v[v] = S(0);
+                if (nxt) sum = cldr_gather<S, VECT, GTF, GT, KT>(ql, mtc, mtw, k * GT, __builtin_amdgcn_readlane(tcn, k));
+#pragma unroll
+                for (int v = 0; v < VECT; ++v) lv[k].v[v] = selfc * qp[k].v[v] - sum.v[v];
+            }
+#pragma unroll
+            for (int k = 0; k < MA; ++k) {
+                const int l = wave + NW * k;
+                if (l < R) epi.row(t, ((size_t)t * g.N + n0 + l) * g.Bp + col0, pc[k], lv[k], acc);
+            }
             if (nxt) {
 #pragma unroll
                 for (int k = 0; k < MP; ++k) {
@@ -740,40 +786,21 @@ __global__ __launch_bounds__(NW * 64) void k_cldr(CldrGeom g, CldrMeta m, const 
                     if (hr >= 0) stl<S, VECT>(Pimg + (size_t)(wave + NW * k) * W + lane * VECT, pn[k]);
                 }
 #pragma unroll
-                for (int k = 0; k < MA; ++k) pcn[k] = pn[k];
-            }
-            if (t + 2 < g.T) {
-                const S* nb = in + (size_t)(t + 2) * slice + col0;
-#pragma unroll
-                for (int k = 0; k < MP; ++k) {
-                    const int hr = __builtin_amdgcn_readlane(hrow, k);
-                    if (hr >= 0) pn[k] = ldv<S, VECT>(nb + (size_t)hr * g.Bp);
-                }
-            }
-            const S selfc = (t > 0 || g.q1) ? S(1) : S(0);
-#pragma unroll
-            for (int k = 0; k < MA; ++k) {
-                const int l = wave + NW * k;
-                if (l < R) {
-                    Vec<S, VECT> sum;
-#pragma unroll
-                    for (int v = 0; v < VECT; ++v) sum.v[v] = S(0);
-                    if (nxt) sum = cldr_gather<S, VECT, GT, KT>(ql, mtc, mtw, k * GT, __builtin_amdgcn_readlane(tcn, k));
-                    Vec<S, VECT> lv;
-#pragma unroll
-                    for (int v = 0; v < VECT; ++v) lv.v[v] = selfc * qp[k].v[v] - sum.v[v];
-                    const size_t off = ((size_t)t * g.N + n0 + l) * g.Bp + col0;
-                    epi.row(t, off, pc[k], lv, acc);
-                }
-            }
-            if (nxt) {
-#pragma unroll
                 for (int k = 0; k < MA; ++k) {
-                    pc[k] = pcn[k];
+                    pc[k] = pn[k];
                     qp[k] = qn[k];
                 }
             }
+            request(pn, t + 1 + CLDR_PREFETCH);
             __syncthreads();                              // P = x_{t+1} complete; every gather from Q is done
+        };
+        if (CLDR_PREFETCH == 2) {
+            for (int t = 0; t < g.T; t += 2) {
+                step(t, pnA);
+                if (t + 1 < g.T) step(t + 1, pnB);
+            }
+        } else {
+            for (int t = 0; t < g.T; ++t) step(t, pnA);
         }
     }
 
