@@ -70,6 +70,7 @@ struct Engine : EngineBase {
         float *dw = nullptr, *tw = nullptr;
     } cldr_dev;
     int use_fused = 1;            // MGADMM_FUSED=0 keeps the two-pass cLdr (tests compare the two)
+    int use_fold = 1;             // MGADMM_FOLD=0: p = r + beta p and x += alpha p stay in their own kernel (EpiPUpdate)
     int cldr_tile_major = 1;      // MGADMM_CLDR_ORDER=0: chunks of a tile adjacent in dispatch order
     int cur_P = 0;                // partial rows written by the last row-kernel launch (k_rows or k_tile)
     int use_tile = 1;             // LDS-tiled spatial kernel on cluster-ordered graphs (reorder = 2); MGADMM_TILE=0 disables
@@ -254,12 +255,14 @@ struct Engine : EngineBase {
     // NW * (MQ + MP) * 64 * VECT * sizeof(S).  MGADMM_CLDR_GEOM selects one (experiments); default per scalar type below.
     template <int VECT_, int NW_, int MA_, int MQ_, int MP_, int MINW_>
     struct ClG { static constexpr int VECT = VECT_, NW = NW_, MA = MA_, MQ = MQ_, MP = MP_, MINW = MINW_; };
+    // measured on cfg3 (N = 10 000, B = 512), SpMM + LHS launch / with the folded vector update:
+    //   geometry 0  365 us / 711 us (13 spilled VGPRs in the folded form)      geometry 1  380 us / 644 us      geometry 2  700 us / -
     typedef ClG<4, 8, 2, 4, 6, 4> ClG0;     // 16 / 32 / 48 rows of 256 columns: 80 KiB (float), two workgroups fill the 160 KiB LDS exactly
-    typedef ClG<4, 8, 2, 4, 5, 4> ClG1;     // 16 / 32 / 40 rows of 256 columns: 72 KiB (float), two workgroups per CU
+    typedef ClG<4, 8, 2, 4, 5, 4> ClG1;     // 16 / 32 / 40 rows of 256 columns: 72 KiB (float), two workgroups per CU   (default)
     typedef ClG<1, 8, 8, 11, 15, sizeof(S) == 4 ? 6 : 2> ClG2;   // 64 / 88 / 120 rows of 64 columns: 52 KiB (float) / 104 KiB (double)
     static constexpr int CL_GT = 12;        // W_d^T slots per row; W_d slots: 6 (no test at all) when no row is longer, else 8
     int cl_gd = 8;
-    int cl_geom = sizeof(S) == 4 ? 0 : 2;   // float64: the narrow geometry (104 KiB)
+    int cl_geom = sizeof(S) == 4 ? 1 : 2;   // float64: the narrow geometry (104 KiB)
     void cl_dims(int& vect, int& nw, int& ma, int& mq, int& mp) const {
         switch (cl_geom) {
             case 0: vect = ClG0::VECT; nw = ClG0::NW; ma = ClG0::MA; mq = ClG0::MQ; mp = ClG0::MP; break;
@@ -330,40 +333,51 @@ struct Engine : EngineBase {
         cl_dims(vect, nw, ma, mq, mp);
         return q.Bp % (64 * vect) == 0 && (sizeof(S) == 4 || vect <= 2);
     }
-    template <class G, template <typename, int> class E, class... A>
-    int rows_cldr_g(const Geom& q, const S* in, const int* live, A... a) {
-        return cl_gd == 6 ? rows_cldr_gd<G, 6, E>(q, in, live, a...) : rows_cldr_gd<G, 8, E>(q, in, live, a...);
+    template <class G, template <typename, int> class E, template <typename, int> class SRC, class... A>
+    int rows_cldr_g(const Geom& q, const SRC<S, G::VECT>& src, const int* live, A... a) {
+        return cl_gd == 6 ? rows_cldr_gd<G, 6, E, SRC>(q, src, live, a...) : rows_cldr_gd<G, 8, E, SRC>(q, src, live, a...);
     }
-    template <class G, int GD, template <typename, int> class E, class... A>
-    int rows_cldr_gd(const Geom& q, const S* in, const int* live, A... a) {
+    template <class G, int GD, template <typename, int> class E, template <typename, int> class SRC, class... A>
+    int rows_cldr_gd(const Geom& q, const SRC<S, G::VECT>& src, const int* live, A... a) {
         const CldrGeom cg = make_cldr_geom(q);
         CldrMeta mm{cldr_dev.n0, cldr_dev.nC, cldr_dev.rows, cldr_dev.dcol, cldr_dev.dw, cldr_dev.dcnt, cldr_dev.tcol, cldr_dev.tw, cldr_dev.tcnt};
         typedef E<S, G::VECT> Epi;
-        auto fn = k_cldr<S, G::VECT, Epi, G::NW, G::MA, G::MQ, G::MP, GD, CL_GT, G::MINW>;
+        auto fn = k_cldr<S, G::VECT, Epi, SRC<S, G::VECT>, G::NW, G::MA, G::MQ, G::MP, GD, CL_GT, G::MINW>;
         MG_TRY(allow_dynamic_lds((const void*)fn, 150 * 1024));
-        hipLaunchKernelGGL(fn, dim3(cg.grid), dim3(G::NW * 64), cg.lds_bytes, st, cg, mm, in, Epi{a...}, partials, live);
+        hipLaunchKernelGGL(fn, dim3(cg.grid), dim3(G::NW * 64), cg.lds_bytes, st, cg, mm, src, Epi{a...}, partials, live);
         cur_P = cg.P;
+        return MGADMM_OK;
+    }
+    template <template <typename, int> class E, template <typename, int> class SRC, class MK, class... A>
+    int rows_cldr_any(const Geom& q, MK mk_src, const int* live, int tag, double bytes, A... a) {
+        const bool timed = prof_open(tag, bytes);
+        int rc;
+        if constexpr (sizeof(S) == 4) {
+            switch (cl_geom) {
+                case 0: rc = rows_cldr_g<ClG0, E, SRC>(q, mk_src(ClG0()), live, a...); break;
+                case 1: rc = rows_cldr_g<ClG1, E, SRC>(q, mk_src(ClG1()), live, a...); break;
+                default: rc = rows_cldr_g<ClG2, E, SRC>(q, mk_src(ClG2()), live, a...); break;
+            }
+        } else {
+            rc = rows_cldr_g<ClG2, E, SRC>(q, mk_src(ClG2()), live, a...);
+        }
+        if (timed) prof_close();
+        MG_TRY(rc);
+        MG_HIP(hipGetLastError());
         return MGADMM_OK;
     }
     // in -> epilogue(l = Ldr^T Ldr in); `passes`: algorithmic vector passes of the launch for the roofline accounting
     template <template <typename, int> class E, class... A>
     int rows_cldr(const Geom& q, const S* in, const int* live, int tag, int passes, A... a) {
         const double bytes = pass_bytes(q, passes) + csr_bytes(g->op_ldr()) + csr_bytes(g->op_ldrt());
-        const bool timed = prof_open(tag, bytes);
-        int rc;
-        if constexpr (sizeof(S) == 4) {
-            switch (cl_geom) {
-                case 0: rc = rows_cldr_g<ClG0, E>(q, in, live, a...); break;
-                case 1: rc = rows_cldr_g<ClG1, E>(q, in, live, a...); break;
-                default: rc = rows_cldr_g<ClG2, E>(q, in, live, a...); break;
-            }
-        } else {
-            rc = rows_cldr_g<ClG2, E>(q, in, live, a...);
-        }
-        if (timed) prof_close();
-        MG_TRY(rc);
-        MG_HIP(hipGetLastError());
-        return MGADMM_OK;
+        return rows_cldr_any<E, CldrSrcPlain>(q, [&](auto gg) { return CldrSrcPlain<S, decltype(gg)::VECT>{in}; }, live, tag, bytes, a...);
+    }
+    // the same with the CG direction formed on load: in = p_new = r + beta p_old; owners store p_new and x += alpha p_old
+    template <template <typename, int> class E, class... A>
+    int rows_cldr_fold(const Geom& q, const S* r, const S* p_old, S* p_new, S* x, const int* live, int tag, int passes, A... a) {
+        const double bytes = pass_bytes(q, passes) + csr_bytes(g->op_ldr()) + csr_bytes(g->op_ldrt());
+        return rows_cldr_any<E, CldrSrcFold>(q, [&](auto gg) { return CldrSrcFold<S, decltype(gg)::VECT>{r, p_old, p_new, x, d_alpha, d_beta}; },
+                                             live, tag, bytes, a...);
     }
 
     int ensure_partials(const Geom& q) {
@@ -386,6 +400,7 @@ struct Engine : EngineBase {
         if (const char* e = getenv("MGADMM_WANT_BLOCKS")) want_blocks = std::max(64, atoi(e));
         if (const char* e = getenv("MGADMM_TILE")) use_tile = atoi(e);
         if (const char* e = getenv("MGADMM_FUSED")) use_fused = atoi(e);
+        if (const char* e = getenv("MGADMM_FOLD")) use_fold = atoi(e);
         if (const char* e = getenv("MGADMM_CLDR_ORDER")) cldr_tile_major = atoi(e);
         Geom q = make_geom(Bmax);
         Bp_max = q.Bp;
@@ -773,15 +788,27 @@ struct Engine : EngineBase {
             else nact_cur = 0;
         }
         const int base = nact_locked ? NACT_LOG : nact_cur;
+        // kind 1 on the fused kernel: the vector update of iteration k (p = r + beta p, x += alpha p) is folded into the
+        // SpMM launch of iteration k+1 (k_cldr with CldrSrcFold); p alternates between two buffers because other tiles
+        // still gather the old direction for their halos.  The x update of the last iteration is applied after the loop.
+        const bool fold = d.kind == 1 && use_fold && cldr_fits(q);
+        S* pbuf[2] = {pp, vec[V_Q]};          // V_Q is free: the fused kernel keeps q = Ldr p on chip
         int k = 0;
         for (; k < K; ++k) {
             const int* live = k == 0 ? nullptr : d_nact + (k - 1);
             prof_cur_ref = (k == 0 || nact_locked) ? -1 : base + k - 1;
-            MG_TRY(lhs_apply(q, d, pp, nullptr, Ap, live));                  // Ap = A p (no mask: quirk Q2)
+            if (fold) {
+                // 2 SpMM applications (16 B/element) + the absorbed vector update (20 B/element) per launch
+                MG_TRY(rows_cldr_fold<EpiLhs>(q, r, pbuf[k & 1], pbuf[(k + 1) & 1], xout, live, 0, 9, (const S*)nullptr, (const S*)nullptr, Ap,
+                                              d.hth, p.t_in, (S)d.c1, (S)d.c2));
+            } else {
+                MG_TRY(lhs_apply(q, d, pp, nullptr, Ap, live));                  // Ap = A p (no mask: quirk Q2)
+            }
             MG_TRY((reduce<1>(q, FinCgAlpha<S>{c, k, q.Bp}, live)));
             MG_TRY(rows<EpiCgUpdate>(q, op_none(), Ap, live, 1, 3, (const S*)d_alpha, r));                 // r -= alpha Ap, r.r
             MG_TRY((reduce<1>(q, FinCgBeta<S>{c, k, q.Bp, p.cg_tol, batch_max}, live)));
-            MG_TRY(rows<EpiPUpdate>(q, op_none(), r, live, 1, 5, (const S*)d_alpha, (const S*)d_beta, xout, pp));   // x += alpha p, p = r + beta p
+            if (!fold)
+                MG_TRY(rows<EpiPUpdate>(q, op_none(), r, live, 1, 5, (const S*)d_alpha, (const S*)d_beta, xout, pp));   // x += alpha p, p = r + beta p
             prof_cur_ref = -1;
             MG_HIP(hipMemcpyAsync(h_nact + base + k, d_nact + k, sizeof(int), hipMemcpyDeviceToHost, st));
             MG_HIP(hipEventRecord(ev_ring[k % (LAG + 1)], st));
@@ -789,6 +816,16 @@ struct Engine : EngineBase {
                 MG_HIP(hipEventSynchronize(ev_ring[(k - LAG) % (LAG + 1)]));
                 if (h_nact[base + k - LAG] == 0) { ++k; break; }
             }
+        }
+        if (fold) {
+            // the last iteration that did work: the first whose active count is 0 (later launches returned at the guard),
+            // else the last one launched; its direction sits in pbuf[(kl + 1) & 1]
+            MG_HIP(hipStreamSynchronize(st));
+            const int launched = std::min(k, K);
+            int kl = launched - 1;
+            for (int j = 0; j < launched; ++j)
+                if (h_nact[base + j] == 0) { kl = j; break; }
+            MG_TRY(rows<EpiXFinal>(q, op_none(), pbuf[(kl + 1) & 1], nullptr, 1, 3, (const S*)d_alpha, xout));
         }
         if (!nact_locked) nact_cur += std::min(k, K);
         if (batch_max) {          // one iteration count for the whole batch: the first iteration after which no sample was above the tolerance

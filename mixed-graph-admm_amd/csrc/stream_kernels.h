@@ -547,20 +547,18 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
 // 64*VECT-column chunk and sweeps t = 0 .. T-1.  For the step t it holds in LDS
 //     P = x_t      on C2 = C1 u {W_d neighbours of C1}      (2-hop set, <= NW*MP rows)
 //     Q = q_{t+1}  on C1 = tile u {W_d^T neighbours of it}  (1-hop set, <= NW*MQ rows), q = Ldr x recomputed on the halo
-// and in registers x_{t+1} and x_{t+2} of its C2 rows (requested two steps ahead), x_t and q_t of its own rows:
+// and in registers x_{t+1} of its C2 rows (requested one step ahead; two steps ahead was measured: 24 more VGPRs, 5 %
+// slower), x_t and q_t of its own rows:
 //     phase A   q_{t+1}[j] = x_{t+1}[j] - sum_e W_d[j,e] P[col_e]            for its rows j of C1   -> Q
 //     barrier
 //     phase C   l_t[i] = [t>0 or q1] q_t[i] - sum_e W_d^T[i,e] Q[col_e]      for its own rows i     -> epilogue
-//               P <- x_{t+1};  request x_{t+3}
+//               P <- x_{t+1};  request x_{t+2}
 //     barrier
 // Local row l of a tile belongs to wave l % NW for all three roles, so the self terms are already in that wave's
 // registers.  Per-row (local column, weight) slots live in VGPR lanes and are broadcast with v_readlane exactly like
 // in k_tile (tables built on the host by build_cldr_tiles, cldr_tiles.h, which has a CPU replay test).  Sums run in
 // CSR entry order and q is rounded to S like the stored q of the two-pass form: the result is BITWISE the same.
 // ---------------------------------------------------------------------------------------------
-#ifndef CLDR_PREFETCH
-#define CLDR_PREFETCH 1      // time steps the rows of x are requested ahead of their use (1 or 2; measured: 2 costs 24 VGPRs and is 5 % slower)
-#endif
 struct CldrGeom {
     int T, N, B, Bp;
     int CH;           // column chunks of 64*VECT
@@ -634,9 +632,32 @@ __device__ __forceinline__ Vec<S, VECT> cldr_gather(const S* __restrict__ img_la
     return sum;
 }
 
+// Where the vector the operator is applied to comes from.
+//   CldrSrcPlain : x = in.
+//   CldrSrcFold  : the CG direction is formed ON LOAD, x = p_new = r + beta p_old (ADMM.py:366), for every row of C2 (the
+//                  halo rows are recomputed like q); the owner of a row also stores p_new and applies the deferred
+//                  x += alpha p_old (ADMM.py:352) -- the whole vector-update kernel of the previous CG iteration
+//                  (EpiPUpdate, 20 B/element) disappears into this launch.  p_new goes to a SECOND buffer: other
+//                  workgroups still read p_old for their halos.
+template <typename S, int VECT>
+struct CldrSrcPlain {
+    static constexpr bool FOLD = false;
+    const S* in;
+};
+template <typename S, int VECT>
+struct CldrSrcFold {
+    static constexpr bool FOLD = true;
+    const S* in;        // r
+    const S* p_old;
+    S* p_new;
+    S* x;
+    const S* alpha;
+    const S* beta;
+};
+
 // MINW: waves per SIMD the register allocation must leave room for (= resident workgroups per CU * NW / 4)
-template <typename S, int VECT, class Epi, int NW, int MA, int MQ, int MP, int GD, int GT, int MINW>
-__global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, const S* __restrict__ in, Epi epi_in,
+template <typename S, int VECT, class Epi, class Src, int NW, int MA, int MQ, int MP, int GD, int GT, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, Src src, Epi epi_in,
                                                   S* __restrict__ partials, const int* __restrict__ live) {
     static_assert(MA <= MQ && MQ <= MP && MP <= 64, "own rows are a prefix of C1, C1 a prefix of C2");
     extern __shared__ __align__(16) unsigned char cldr_raw[];
@@ -705,48 +726,90 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, 
         const S* pl = Pimg + lane * VECT;
         const S* ql = Qimg + lane * VECT;
         const size_t slice = (size_t)g.N * g.Bp;
-        Vec<S, VECT> pnA[MP], pnB[MP];  // x_{t+1} / x_{t+2} of this wave's rows of C2: requested TWO steps ahead, the buffers alternate
+        constexpr int MPF = Src::FOLD ? MP : 1, MAF = Src::FOLD ? MA : 1;
+        Vec<S, VECT> pn[MP];            // x_{t+1} of this wave's rows of C2 (requested one step ahead; FOLD: r_{t+1})
+        Vec<S, VECT> po[MPF], xo[MAF];  // FOLD: p_old of the same rows, x of the own rows
         Vec<S, VECT> pc[MA], qp[MA];    // x_t and q_t of its own rows
+        S fa[VECT], fb[VECT];           // FOLD: alpha, beta of this lane's columns
+#pragma unroll
+        for (int v = 0; v < VECT; ++v) fa[v] = fb[v] = S(0);
+        if constexpr (Src::FOLD) {
+#pragma unroll
+            for (int v = 0; v < VECT; ++v) {
+                fa[v] = src.alpha[col0 + v];
+                fb[v] = src.beta[col0 + v];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < MP; ++k)
 #pragma unroll
-            for (int v = 0; v < VECT; ++v) pnA[k].v[v] = pnB[k].v[v] = S(0);   // row slots past |C2| are never loaded
-        // prologue: x_0 -> P image, q_0 = 0, request x_1 and x_2
-#pragma unroll
-        for (int k = 0; k < MP; ++k) {
-            const int hr = __builtin_amdgcn_readlane(hrow, k);
-            if (hr >= 0) pnA[k] = ldv<S, VECT>(in + (size_t)hr * g.Bp + col0);
-        }
-#pragma unroll
-        for (int k = 0; k < MP; ++k) {
-            const int hr = __builtin_amdgcn_readlane(hrow, k);
-            if (hr >= 0) stl<S, VECT>(Pimg + (size_t)(wave + NW * k) * W + lane * VECT, pnA[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < MA; ++k) {
-            pc[k] = pnA[k];
-#pragma unroll
-            for (int v = 0; v < VECT; ++v) qp[k].v[v] = S(0);
-        }
-        auto request = [&](Vec<S, VECT> (&pn)[MP], int tt) {
+            for (int v = 0; v < VECT; ++v) pn[k].v[v] = S(0);     // row slots past |C2| are never loaded
+        // rows of time slice tt -> registers
+        auto request = [&](int tt) {
             if (tt < g.T) {
-                const S* nb = in + (size_t)tt * slice + col0;
+                const size_t so = (size_t)tt * slice + col0;
 #pragma unroll
                 for (int k = 0; k < MP; ++k) {
                     const int hr = __builtin_amdgcn_readlane(hrow, k);
-                    if (hr >= 0) pn[k] = ldv<S, VECT>(nb + (size_t)hr * g.Bp);
+                    if (hr >= 0) {
+                        pn[k] = ldv<S, VECT>(src.in + so + (size_t)hr * g.Bp);
+                        if constexpr (Src::FOLD) po[k] = ldv<S, VECT>(src.p_old + so + (size_t)hr * g.Bp);
+                    }
+                }
+                if constexpr (Src::FOLD) {
+#pragma unroll
+                    for (int k = 0; k < MA; ++k)
+                        if (wave + NW * k < R) xo[k] = ldv<S, VECT>(src.x + so + (size_t)(n0 + wave + NW * k) * g.Bp);
                 }
             }
         };
-        request(pnA, 1);
-        if (CLDR_PREFETCH == 2) request(pnB, 2);
+        // FOLD: the requested rows of slice tt become p_new = r + beta p_old; own rows: x += alpha p_old, p_new stored
+        auto combine = [&](int tt) {
+            if constexpr (Src::FOLD) {
+#pragma unroll
+                for (int k = 0; k < MP; ++k) {
+                    const int hr = __builtin_amdgcn_readlane(hrow, k);
+                    if (hr >= 0) {
+                        Vec<S, VECT> pv;
+#pragma unroll
+                        for (int v = 0; v < VECT; ++v) pv.v[v] = fma(fb[v], po[k].v[v], pn[k].v[v]);
+                        if (k < MA) {
+                            if (wave + NW * k < R) {
+                                const size_t off = (size_t)tt * slice + (size_t)(n0 + wave + NW * k) * g.Bp + col0;
+                                Vec<S, VECT> xv;
+#pragma unroll
+                                for (int v = 0; v < VECT; ++v) xv.v[v] = fma(fa[v], po[k].v[v], xo[k < MAF ? k : 0].v[v]);
+                                stv<S, VECT>(src.x + off, xv);
+                                stv<S, VECT>(src.p_new + off, pv);
+                            }
+                        }
+                        pn[k] = pv;
+                    }
+                }
+            }
+        };
+        // prologue: x_0 -> P image, q_0 = 0, request x_1
+        request(0);
+        combine(0);
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            const int hr = __builtin_amdgcn_readlane(hrow, k);
+            if (hr >= 0) stl<S, VECT>(Pimg + (size_t)(wave + NW * k) * W + lane * VECT, pn[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < MA; ++k) {
+            pc[k] = pn[k];
+#pragma unroll
+            for (int v = 0; v < VECT; ++v) qp[k].v[v] = S(0);
+        }
+        request(1);
         __syncthreads();
-        // one time step; pn holds x_{t+1} on entry and is re-requested with x_{t+3} as soon as it has been consumed
-        auto step = [&](int t, Vec<S, VECT> (&pn)[MP]) {
+        for (int t = 0; t < g.T; ++t) {
             const bool nxt = t + 1 < g.T;
             Vec<S, VECT> qn[MA];
-            // ---- phase A: q_{t+1} on this wave's rows of C1
+            // ---- phase A: q_{t+1} on this wave's rows of C1 (pn holds x_{t+1}, requested during the previous step)
             if (nxt) {
+                combine(t + 1);
                 // one LDS round trip per row (the first GDF slots are read together); row slots past |C1| are skipped
 #pragma unroll
                 for (int k = 0; k < MQ; ++k) {
@@ -762,7 +825,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, 
                 }
             }
             __syncthreads();                              // Q complete; every gather from P is done
-            // ---- phase C: own rows of l_t through the epilogue, then P <- x_{t+1} and the request of x_{t+3}
+            // ---- phase C: own rows of l_t through the epilogue, then P <- x_{t+1} and the request of x_{t+2}
             const S selfc = (t > 0 || g.q1) ? S(1) : S(0);
             Vec<S, VECT> lv[MA];
 #pragma unroll
@@ -791,16 +854,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, 
                     qp[k] = qn[k];
                 }
             }
-            request(pn, t + 1 + CLDR_PREFETCH);
+            request(t + 2);
             __syncthreads();                              // P = x_{t+1} complete; every gather from Q is done
-        };
-        if (CLDR_PREFETCH == 2) {
-            for (int t = 0; t < g.T; t += 2) {
-                step(t, pnA);
-                if (t + 1 < g.T) step(t + 1, pnB);
-            }
-        } else {
-            for (int t = 0; t < g.T; ++t) step(t, pnA);
         }
     }
 
@@ -973,11 +1028,35 @@ struct EpiPUpdate {
         Vec<S, VEC> pv = o.p, xv = o.x;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            xv.v[v] = xv.v[v] + a[v] * pv.v[v];
-            pv.v[v] = rv.v[v] + b[v] * pv.v[v];
+            xv.v[v] = fma(a[v], pv.v[v], xv.v[v]);       // explicit fma: the same rounding as the form folded into k_cldr
+            pv.v[v] = fma(b[v], pv.v[v], rv.v[v]);
         }
         stv<S, VEC>(x + off, xv);
         stv<S, VEC>(p + off, pv);
+    }
+};
+
+// x += alpha p (ADMM.py:352) for the LAST iteration of a CG solve whose p-updates are folded into the SpMM kernel
+template <typename S, int VEC>
+struct EpiXFinal {
+    static constexpr bool ELEMENTWISE = true;
+    static constexpr int NRED = 0;
+    static constexpr bool HAS_PRE = false;
+    const S* alpha;
+    S* x;
+    S a[VEC];
+    __device__ void begin(int col0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) a[v] = alpha[col0 + v];
+    }
+    struct Ops { Vec<S, VEC> x; };
+    __device__ Ops fetch(size_t off) const { return Ops{ldv<S, VEC>(x + off)}; }
+    __device__ void row(int t, size_t off, const Vec<S, VEC>& pv, const Vec<S, VEC>& l, S (*acc)[VEC]) { row_ops(t, off, pv, l, acc, fetch(off)); }
+    __device__ void row_ops(int, size_t off, const Vec<S, VEC>& pv, const Vec<S, VEC>&, S (*)[VEC], const Ops& o) {
+        Vec<S, VEC> xv = o.x;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) xv.v[v] = fma(a[v], pv.v[v], xv.v[v]);
+        stv<S, VEC>(x + off, xv);
     }
 };
 
