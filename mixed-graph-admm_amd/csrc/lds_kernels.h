@@ -5,8 +5,9 @@
 // every residual / regulariser of the history.  Inside a CG solve nothing touches HBM:
 //   * thread (g, i) owns node i at TPG consecutive time steps t0 = g*TPG ...; x, r, p, Ap of those
 //     elements live in registers for the whole solve;
-//   * a copy of the CG direction p (and of q = Ldr p) lives in LDS so that neighbours can be gathered --
-//     the only LDS traffic of an iteration is those gathers (aligned ds_read_b128) and one store of p and q;
+//   * a copy of the CG direction p (and of q = Ldr p) lives in LDS so that neighbours can be gathered, stored SHIFTED by
+//     the time offset of the operator that reads it (LdsCtx::put), so that every gather is an aligned ds_read_b128 run --
+//     the only LDS traffic of an iteration is those gathers and one store of p and q;
 //   * the three CSR matrices (W_u, W_d, W_d^T as packed {col, weight} pairs) live in LDS too; a thread
 //     reads each entry of ITS node's row once per operator application and applies it to its TPG time steps;
 //   * p.Ap and r.r are reduced with wave shuffles + a 16-entry LDS exchange in fixed order (repeatable);
@@ -132,44 +133,17 @@ struct LdsCtx {
     __device__ __forceinline__ int gl(int k) const { return (t0 + k) * N + i; }   // HBM index
     __device__ __forceinline__ int own() const { return i * TS + t0; }            // LDS index of element k = 0
 
-    // One CSR entry's window of the neighbour row: v[k] = SRC[col][t0+k] with, for a shifted gather, the edge
-    // element (t0-1 resp. t0+TPG, 0 outside [0,T)) in the slot of the window element the shift does not use
-    // (v[TPG-1] resp. v[0]) -- i.e. the window ROTATED by one, so that acc[k] += w*v[k] needs no register
-    // shuffles for the packed FMAs; gather() undoes the rotation once after its loop.
-    //   A shifted window [t0-1, t0+TPG-2] or [t0+1, t0+TPG] is read as the ALIGNED run [t0, t0+TPG-1] plus one
-    //   more aligned 16-byte group holding the edge element: every read is a conflict-free ds_read_b128
-    //   (unaligned b96 / read2_b32 forms use 32 banks and collide 4-way at this row stride).  The empty asm
-    //   statements stop the compiler from narrowing the vector loads to the components that are used.
-    __device__ __forceinline__ void fetch(const float* base, int coloff, int shift, float (&v)[TPG]) const {
-        const float* row = base + coloff;
-        lds_load<TPG>(row, v);
-        if (shift == 0) return;
-        if (TPG == T) {                      // the thread owns the whole time axis: the element beyond either end is 0
-            v[shift < 0 ? TPG - 1 : 0] = 0.f;
-            return;
-        }
-        const bool lo_ok = t0 > 0, hi_ok = t0 + TPG < T;
-        float edge;
-        if constexpr (TPG % 4 == 0) {
-            const int goff = shift < 0 ? (lo_ok ? -4 : 0) : TPG;      // TS >= T + 4 pads the tail (or the next row follows)
-            float eg[4];
-            lds_load<4>(row + goff, eg);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(eg[k]));
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) asm volatile("" ::"v"(v[k]));
-            edge = shift < 0 ? (lo_ok ? eg[3] : 0.f) : (hi_ok ? eg[0] : 0.f);   // select: the pad words are not initialised
-        } else {
-            const int eoff = shift < 0 ? (lo_ok ? -1 : 0) : (hi_ok ? TPG : TPG - 1);
-            const float emask = shift < 0 ? (lo_ok ? 1.f : 0.f) : (hi_ok ? 1.f : 0.f);
-            edge = row[eoff] * emask;
-        }
-        v[shift < 0 ? TPG - 1 : 0] = edge;
-    }
-    // acc[k] = sum_e w_e * SRC[col_e][t0+k+shift]     (0 outside [0,T)).  Entries carry the LDS float offset of
-    // the neighbour's row (col*TS, precomputed on the host).  Two entries are in flight per trip (their LDS
-    // reads are issued together, the next pair of entries is fetched meanwhile); the sum runs in entry order.
-    __device__ __forceinline__ void gather(const float* SRC, const int2* EN, int e0, int e1, int shift, float (&acc)[TPG]) const {
+    // SHIFTED LDS IMAGES.  A vector that is only gathered through a time-shifted operator is stored shifted: the image
+    // read by Ldr (gathers x[t-1]) holds time t-1 at index t, the image read by Ldr^T (gathers x[t+1]) holds time t+1 at
+    // index t, 0 outside [0,T).  Every gather of a neighbour's TPG-step window is then the ALIGNED run [t0, t0+TPG-1]:
+    // conflict-free ds_read_b128 only, no edge group, no rotation of the accumulators (round 1 read an aligned run plus
+    // one more 16-byte group holding the edge element: 3 reads per entry at TPG = 8 instead of 2).  The price is the
+    // store of the own elements, unaligned by one float (scalar ds_write_b32; stores are 1/15 of the LDS traffic).
+    //
+    // acc[k] = sum_e w_e * IMG[col_e][t0+k].  Entries carry the LDS float offset of the neighbour's row (col*TS,
+    // precomputed on the host).  Two entries are in flight per trip (their LDS reads are issued together, the next pair
+    // of entries is fetched meanwhile); the sum runs in entry order.
+    __device__ __forceinline__ void gather(const float* SRC, const int2* EN, int e0, int e1, float (&acc)[TPG]) const {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
         const float* base = SRC + t0;
@@ -178,8 +152,8 @@ struct LdsCtx {
         for (; e + 1 < e1; e += 2) {
             const int2 ea = na, eb = nb;
             float va[TPG], vb[TPG];
-            fetch(base, ea.x, shift, va);
-            fetch(base, eb.x, shift, vb);
+            lds_load<TPG>(base + ea.x, va);
+            lds_load<TPG>(base + eb.x, vb);
             na = EN[e + 2];
             nb = EN[e + 3];
             const float wa = __int_as_float(ea.y), wb = __int_as_float(eb.y);
@@ -190,21 +164,10 @@ struct LdsCtx {
         }
         if (e < e1) {
             float va[TPG];
-            fetch(base, na.x, shift, va);
+            lds_load<TPG>(base + na.x, va);
             const float wa = __int_as_float(na.y);
 #pragma unroll
             for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
-        }
-        if (shift < 0) {
-            const float last = acc[TPG - 1];
-#pragma unroll
-            for (int k = TPG - 1; k >= 1; --k) acc[k] = acc[k - 1];
-            acc[0] = last;
-        } else if (shift > 0) {
-            const float first = acc[0];
-#pragma unroll
-            for (int k = 0; k < TPG - 1; ++k) acc[k] = acc[k + 1];
-            acc[TPG - 1] = first;
         }
     }
     // band (line-graph) stencils on the node's own time row
@@ -237,14 +200,14 @@ struct LdsCtx {
     // l = Lu(src): neighbours from SRC (LDS), the thread's own elements of src from registers (self)     ADMM.py:138-148
     __device__ __forceinline__ void op_lu(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
         float acc[TPG];
-        gather(SRC, en_u, u0, u1, 0, acc);
+        gather(SRC, en_u, u0, u1, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = self[k] - acc[k];
     }
     // l = Ldr(src)      ADMM.py:150-177
     __device__ __forceinline__ void op_ldr(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
         float acc[TPG];
-        if constexpr (!BAND) gather(SRC, en_d, d0, d1, -1, acc);
+        if constexpr (!BAND) gather(SRC, en_d, d0, d1, acc);       // SRC: image stored with put<-1>
         else band_back(SRC, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((k >= 1 || t0 >= 1) ? self[k] : 0.f) - acc[k];
@@ -252,14 +215,28 @@ struct LdsCtx {
     // l = Ldr_T(src)    ADMM.py:179-223 (q1: identity kept on the t=0 block)
     __device__ __forceinline__ void op_ldrt(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
         float acc[TPG];
-        if constexpr (!BAND) gather(SRC, en_t, t0e, t1e, +1, acc);
+        if constexpr (!BAND) gather(SRC, en_t, t0e, t1e, acc);     // SRC: image stored with put<+1>
         else band_fwd(SRC, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((k > 0 || t0 > 0 || q1) ? self[k] : 0.f) - acc[k];
     }
-    // own elements -> LDS vector
+    // own elements -> LDS image read by an operator that gathers time t + SH (SH = 0: Lu and the band stencils, -1: Ldr,
+    // +1: Ldr^T): index j of a node's row holds time j + SH, 0 outside [0,T)
+    template <int SH>
     __device__ __forceinline__ void put(float* DST, const float (&v)[TPG]) const {
-        if (active) lds_store<TPG>(DST + own(), v);
+        if (!active) return;
+        if constexpr (SH == 0 || BAND) {
+            lds_store<TPG>(DST + own(), v);
+        } else {
+            float* row = DST + i * TS + t0 - SH;            // index of element k = 0
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) {
+                const bool ok = SH < 0 ? (k < TPG - 1 || t0 + TPG < T) : (k > 0 || t0 > 0);   // index T resp. -1 does not exist
+                if (ok) row[k] = v[k];
+            }
+            if (SH < 0 && t0 == 0) DST[i * TS] = 0.f;                      // time -1
+            if (SH > 0 && t0 + TPG == T) DST[i * TS + T - 1] = 0.f;        // time T
+        }
     }
     // own elements -> HBM state vector (sample base already applied)
     __device__ __forceinline__ void putg(float* DST, const float (&v)[TPG]) const {
@@ -287,7 +264,7 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND>& c, const flo
         for (int k = 0; k < TPG; ++k) q[k] = 0.f;
         if (c.active) c.op_ldr(c.P, v, q);
         if (SB) __syncthreads();           // single LDS vector (Q aliases P): every gather of p is done before q replaces it
-        c.put(c.Q, q);
+        c.template put<+1>(c.Q, q);
         __syncthreads();
         if (c.active) c.op_ldrt(c.Q, q, l);
     } else if (KIND == 2) {
@@ -320,8 +297,9 @@ template <int TPG, bool BAND, int KIND, bool SB>
 __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
                       int hth, int t_in, float c1, float c2, int max_cg, double tol, float* ah, float* bh, int Bp,
                       int* nonfinite) {
+    constexpr int SHP = KIND == 1 ? -1 : 0;     // the image of the CG direction: read by Ldr (cLdr solves) or by Lu
     float r[TPG], pv[TPG], av[TPG], dc[TPG];
-    c.put(c.P, x);
+    c.template put<SHP>(c.P, x);
     __syncthreads();
     lds_diag<TPG, BAND>(c, dmask, hth, t_in, c1, dc);
     (void)lds_apply<TPG, BAND, KIND, SB>(c, x, av, dc, c2);
@@ -334,7 +312,7 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, 
         part += r[k] * r[k];
     }
     float rr = br.sumf(part);            // barrier: every read of P (= x0) is done
-    c.put(c.P, pv);
+    c.template put<SHP>(c.P, pv);
     int iters = -1;
     for (int it = 0; it < max_cg; ++it) {
         __syncthreads();                 // p complete in LDS
@@ -365,7 +343,7 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, 
         }
 #pragma unroll
         for (int k = 0; k < TPG; ++k) pv[k] = r[k] + beta * pv[k];
-        c.put(c.P, pv);
+        c.template put<SHP>(c.P, pv);
     }
     return iters;
 }
@@ -443,7 +421,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         float ph[TPG];
 #pragma unroll
         for (int k = 0; k < TPG; ++k) ph[k] = 0.f;
-        c.put(P, x);
+        c.template put<-1>(P, x);
         __syncthreads();
         if (c.active) c.op_ldr(P, x, ph);
         c.putg(phi, ph);
@@ -459,7 +437,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = 0.f;
         if (a.has_phi) {
-            c.put(P, v);
+            c.template put<+1>(P, v);
             __syncthreads();
             if (c.active) c.op_ldrt(P, v, l);
             __syncthreads();
@@ -595,7 +573,8 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     // ---- phi prox, gamma update, Ldr/Lu based diagnostics (ADMM.py:600-606, 619, 627-637); xr = x_new, zn = phi_old, gn = gamma
     double m_priphi = 0, m_dualphi = 0, m_dgtv = 0, m_dglr = 0, m_glr = 0;
     __syncthreads();          // every LDS read of the last CG is done
-    c.put(P, xr);
+    c.template put<-1>(P, xr);        // read by Ldr
+    if (!SB) c.template put<0>(Q, xr);   // read by Lu (GLR); SB: Q aliases P, see below
     __syncthreads();
     if (c.active) {
         float l[TPG];
@@ -618,9 +597,22 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
                 gam[e] = gv + a.rho * dd;
             }
         }
-        c.op_lu(P, xr, l);
+        if (!SB) {
+            c.op_lu(Q, xr, l);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) m_glr += (double)xr[k] * (double)l[k];
+            for (int k = 0; k < TPG; ++k) m_glr += (double)xr[k] * (double)l[k];
+        }
+    }
+    if (SB) {                 // one LDS vector: the unshifted image replaces the shifted one after every Ldr gather is done
+        __syncthreads();
+        c.template put<0>(P, xr);
+        __syncthreads();
+        if (c.active) {
+            float l[TPG];
+            c.op_lu(P, xr, l);
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) m_glr += (double)xr[k] * (double)l[k];
+        }
     }
 
     emit(MGADMM_M_PRI_PHI, m_priphi, a.has_phi);

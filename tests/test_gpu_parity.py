@@ -533,3 +533,43 @@ def test_tiled_kernel_full_solves(g4_meta, g4_solves, dt, xtol, htol, slack, mon
     xb = b.combined_loop(torch.from_numpy(y), print_info=False)
     assert rel(xa, xb) < (1e-12 if dt == torch.float64 else 1e-5)
     a.close(); b.close()
+
+
+# ------------------------------------------------------------------ fused cLdr kernel (k_cldr): every tile geometry
+@pytest.mark.parametrize("geom,B,fold", [(0, 256, 1), (1, 256, 1), (1, 256, 0), (2, 70, 1), (2, 256, 1)])
+def test_fused_cldr_kernel_geometries_vs_oracle(geom, B, fold, monkeypatch):
+    """k_cldr = Ldr^T Ldr in one pass with q recomputed on the tile halo, with and without the CG vector update folded
+    into its loads (CldrSrcFold), in each of its tile geometries (256 / 64 columns per row): operators, one CG solve and a
+    whole 4-iteration solve against the oracle on the 30-node golden graph (several tiles: clusters are cut at the caps)."""
+    from mgadmm import _lib
+    monkeypatch.setenv("MGADMM_CLDR_GEOM", str(geom))
+    monkeypatch.setenv("MGADMM_FOLD", str(fold))
+    meta = load_golden("g4_meta.npz")
+    rng = np.random.default_rng(geom * 10 + fold)
+    x = rng.standard_normal((B, 24, 30, 1)).astype(np.float32)
+    o = make_oracle(meta, "knn")
+    blk = make_product(meta, "knn", compute_dtype=torch.float32, path="stream", reorder="cluster")
+    xt = torch.from_numpy(x)
+    assert rel(blk.apply_op_cLdr(xt), o.apply_op_cLdr(x.astype(np.float64))) < 2e-6
+    assert rel(blk.LHS_x(xt), o.LHS_x(x.astype(np.float64))) < 2e-6
+    assert rel(blk.LHS_zd(xt), o.LHS_zd(x.astype(np.float64))) < 2e-6
+    k = 6                                                   # the oracle solves a few of the B systems
+    rhs = (rng.standard_normal((B, 24, 30, 1)) * np.logspace(-1, 1, B).reshape(B, 1, 1, 1)).astype(np.float32)
+    for fn_p, fn_o in ((blk.LHS_x, o.LHS_x), (blk.LHS_zd, o.LHS_zd)):
+        xs, it, _, _ = blk.CG_solver(fn_p, torch.from_numpy(rhs), xt)
+        xo, ito, _, _ = o.CG_solver(fn_o, rhs[:k].astype(np.float64), x[:k].astype(np.float64))
+        assert rel(xs[:k], xo) < 1e-5 and np.abs(it[:k].numpy() - ito).max() <= 1
+    y = 100 + 50 * rng.random((B, 12, 30, 1)).astype(np.float32)
+    blk.max_ADMM_iter = 4
+    blk.check_stop = False
+    xs = blk.solve(torch.from_numpy(y), per_sample_history=True, return_state=False)[0]
+    xo = o.combined_loop(y[:k].astype(np.float64), n_iters=4)
+    assert rel(xs[:k], xo) < 1e-5
+    mps = blk.metrics_per_sample[:, :, :k]
+    np.testing.assert_allclose(np.sqrt(mps[:, _lib.M_PRI_ZD].sum(1)), np.array(o.hist.p_res_list)[:, 2], rtol=1e-3)
+    np.testing.assert_allclose(np.sqrt(mps[:, _lib.M_PRI_PHI].sum(1)), np.array(o.hist.p_res_list)[:, 1], rtol=1e-3)
+    got = torch.stack(blk.CG_iter_x).numpy()[:, :k]
+    assert np.abs(got - np.array(o.hist.CG_iter_x)).max() <= 1
+    h = blk._solvers[(1, torch.float32)][0]
+    assert _lib.query(h, _lib.Q_TILE_ROWS) == 8
+    blk.close()

@@ -1,20 +1,25 @@
 """Turn the three rocprofv3 passes of one bench command into the committed summary + profiles/traffic.json.
 
-    python tools/make_profile_summary.py gpurun_out/profN profiles/r01/NAME.txt "<bench command>"
+    python tools/make_profile_summary.py <dir> profiles/rNN/NAME.txt "<bench command>"
 
 expects  <dir>/stats  (--kernel-trace --stats), <dir>/fetch (--pmc FETCH_SIZE), <dir>/write (--pmc WRITE_SIZE):
 separate runs, as MI355X_MICROARCH.md prescribes.  gfx950 correction: FETCH_SIZE under-reports wide
 coalesced streaming reads by exactly 2x -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KB.
+A launch is "live" when its duration / counter exceeds half of the kernel's maximum: the speculative CG launches that
+found their solve converged return at the guard after a few microseconds and move nothing.
 """
 import collections, csv, glob, json, os, re, statistics as st, sys
 
 
 def short(n):
     n = n.replace('void ', '')
+    m = re.search(r'k_cldr<(\w+), (\d+), (\w+)<[^>]*>, CldrSrc(\w+)<[^>]*>, (\d+), (\d+), (\d+), (\d+)', n)
+    if m:
+        return f"k_cldr<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)}>"
     m = re.search(r'(k_rows|k_tile)<(\w+), (\d+), (\w+)(?:<[^>]*>)?, (\d+)', n)
     if m:
         return f"{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)},GW{m.group(5)}>"
-    m = re.search(r'k_admm_lds<(\d+), (\w+)>', n)
+    m = re.search(r'k_admm_lds<(\d+), (\w+), (\d+), (\w+)>', n)
     if m:
         return f"k_admm_lds<{m.group(1)},{m.group(2)}>"
     return n.split('(')[0][:52]
@@ -43,6 +48,10 @@ def live_mean(v):
     return st.mean(lv), len(lv)
 
 
+def is_spmm_in_cg(k):
+    return (k.startswith('k_tile') and ('EpiLhs' in k or 'EpiStore' in k)) or (k.startswith('k_cldr') and 'EpiLhs' in k)
+
+
 def main():
     d, out, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
     dur = durations(d + '/stats')
@@ -50,21 +59,22 @@ def main():
     tot = sum(sum(v) for v in dur.values())
     L = [f"# rocprofv3 --kernel-trace --stats -- {cmd}",
          "# default cfg2 workload (N=307, B=4096: LDS-resident path, k_admm_lds) followed by the cfg3 roofline leg",
-         "# (N=10000, B=512: streaming path; spatial operators in the LDS-tiled k_tile, element-wise work in k_rows).",
+         "# (N=10000, B=512: streaming path; cLdr inside the x / zd solves = fused k_cldr with the CG vector update folded in,",
+         "# Lu and the single operators in the LDS-tiled k_tile, element-wise work in k_rows).",
          "# live = launches that did the work (duration > 50 % of the kernel's longest launch); the others are speculative CG",
          "# launches that found their solve converged and returned at the guard.  bench.py's roofline objects use live launches only.",
          f"{'kernel':52s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>10s} {'pct':>6s} {'n_live':>7s} {'live_avg_us':>12s}"]
-    for k in sorted(dur, key=lambda k: -sum(dur[k]))[:24]:
+    for k in sorted(dur, key=lambda k: -sum(dur[k]))[:26]:
         v = dur[k]
         lm, ln = live_mean(v)
         L.append(f"{k:52s} {len(v):6d} {st.mean(v):10.1f} {sum(v) / 1e3:10.2f} {100 * sum(v) / tot:6.1f} {ln:7d} {lm:12.1f}")
-    mix = [k for k in dur if k.startswith('k_tile') and ('EpiLhs' in k or 'EpiStore' in k)]
+    mix = [k for k in dur if is_spmm_in_cg(k)]
     if mix:
         lv = {k: [x for x in dur[k] if x > 0.5 * max(dur[k])] for k in mix}
         nl = sum(len(v) for v in lv.values())
         L += ["", f"# SpMM inside CG on the cfg3 leg = {', '.join(sorted(mix))}: {nl} live launches, average "
                   f"{sum(sum(v) for v in lv.values()) / nl:.1f} us -- compare bench.py's",
-              "# roofline_cfg3.avg_launch_us, which times the same live launch mix with HIP events"]
+              "# roofline.cfg3_spmm_avg_launch_us, which times the same live launch mix with HIP events"]
     lds = [k for k in dur if k.startswith('k_admm_lds')]
     if lds:
         L += [f"# {lds[0]}: average {st.mean(dur[lds[0]]):.1f} us over {len(dur[lds[0]])} launches (bench.py roofline.avg_launch_us; the first"
@@ -72,19 +82,18 @@ def main():
     L += ["", "# PMC passes (separate runs): FETCH_SIZE / WRITE_SIZE in KB per dispatch, mean over LIVE dispatches (dispatches",
           "# skipped by the converged-CG early exit are excluded: counter > 50% of the kernel's max).",
           "# hbm_MB = (2*FETCH_SIZE + WRITE_SIZE) KB / 1e3   (gfx950: FETCH_SIZE under-reports 16 B/lane streaming reads by 2x)",
-          f"{'kernel':44s} {'n_live':>6s} {'FETCH_KB':>10s} {'WRITE_KB':>10s} {'hbm_MB':>10s} {'live_avg_us':>12s}"]
+          f"{'kernel':44s} {'n_live':>6s} {'FETCH_KB':>10s} {'WRITE_KB':>10s} {'hbm_MB':>10s} {'live_avg_us':>12s} {'TB/s':>7s}"]
     per = {}
     for k in sorted(fetch, key=lambda k: -sum(dur.get(k, [0]))):
-        if not (k.startswith('k_rows') or k.startswith('k_tile') or k.startswith('k_admm')):
+        if not (k.startswith('k_rows') or k.startswith('k_tile') or k.startswith('k_admm') or k.startswith('k_cldr')):
             continue
         f, n = live_mean(fetch[k])
         w, _ = live_mean(write.get(k, [0]))
         du, _ = live_mean(dur[k]) if k in dur else (0, 0)
         per[k] = (2 * f + w) * 1024.0
-        L.append(f"{k:44s} {n:6d} {f:10.0f} {w:10.0f} {per[k] / 1e6:10.1f} {du:12.1f}")
+        L.append(f"{k:44s} {n:6d} {f:10.0f} {w:10.0f} {per[k] / 1e6:10.1f} {du:12.1f} {per[k] / max(du, 1e-9) / 1e6:7.2f}")
     open(out, 'w').write("\n".join(L) + "\n")
-    # SpMM-in-CG kernels of the cfg3 leg: EpiLhs (GW4/GW8) and EpiStore, weighted by live launch counts
-    spmm = [k for k in per if k.startswith('k_tile') and ('EpiLhs' in k or 'EpiStore' in k)]
+    spmm = [k for k in per if is_spmm_in_cg(k)]
     wts = {k: live_mean(fetch[k])[1] for k in spmm}
     tj = {"_source": f"{out}: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (separate runs) of `{cmd}`; "
                      "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE under-reports 16 B/lane streaming reads by 2x); "
