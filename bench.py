@@ -209,9 +209,9 @@ def load_traffic(workload):
 
 def lds_bytes_per_launch(blk, B, cg, T=24):
     """LDS bytes one k_admm_lds launch (= one ADMM iteration of B samples) moves, counted from what the kernel issues
-    (csrc/lds_kernels.h): per CSR entry and time group one entry read (8 B) + ceil(TPG/4) aligned 16-B row reads, + one
-    more 16-B group holding the edge element for the time-shifted operators; per operator application one 4-B store per
-    element.  Operator applications: x / zd solves (K+1) x (Ldr + Ldr^T), zu solve (K+1) x Lu, + RHS_x (Ldr^T),
+    (csrc/lds_kernels.h): per CSR entry and time group one entry read (8 B) + ceil(TPG/4) aligned 16-B row reads (the
+    images gathered by the time-shifted operators are stored shifted: no edge reads); per operator application one 4-B
+    store per element.  Operator applications: x / zd solves (K+1) x (Ldr + Ldr^T), zu solve (K+1) x Lu, + RHS_x (Ldr^T),
     phi prox (Ldr) and GLR (Lu).  K = measured mean CG iterations of the timed solve."""
     from mgadmm import _lib
     h = blk._solvers[(1, torch.float32)][0]
@@ -219,7 +219,7 @@ def lds_bytes_per_launch(blk, B, cg, T=24):
     G = T // tpg
     nu, nd, nt = (_lib.query(h, q) for q in (_lib.Q_NNZ_U, _lib.Q_NNZ_D, _lib.Q_NNZ_DT))
     run = ((tpg + 3) // 4) * 16 if tpg % 4 == 0 else tpg * 4
-    edge = 16 if tpg % 4 == 0 else 4
+    edge = 0          # round 2: shifted LDS images (LdsCtx::put<SH>), the edge element comes with the aligned run
     per_lu = G * nu * (8 + run)
     per_ldr = G * nd * (8 + run + edge)
     per_ldrt = G * nt * (8 + run + edge)

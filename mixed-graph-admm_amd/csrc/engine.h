@@ -78,7 +78,7 @@ struct Engine : EngineBase {
     // LDS-resident fused path (float32, small graphs)
     struct LdsPlan {
         bool ok = false;
-        int G = 0, TPG = 0, TS = 0, nthreads = 0, block = 0, csr_ints = 0, maxt = 1024, sb = 0;
+        int G = 0, TPG = 0, TS = 0, nthreads = 0, block = 0, csr_ints = 0, maxt = 1024, sb = 0, uniform45 = 0;
         int off_rp_u = 0, off_rp_d = 0, off_rp_t = 0, off_en_u = 0, off_en_d = 0, off_en_t = 0;
         size_t lds_bytes = 0;
     } lds;
@@ -1301,6 +1301,10 @@ struct Engine : EngineBase {
         lds.nthreads = N * lds.G;
         lds.block = (lds.nthreads + 63) / 64 * 64;
         lds.sb = sb ? 1 : 0;
+        // kNN tables with k = 4 and no pads (the reference's setting): every W_u row has 4, every W_d row 5 entries
+        lds.uniform45 = (!band && !getenv("MGADMM_LDS_RAGGED")) ? 1 : 0;
+        for (int i = 0; i < N && lds.uniform45; ++i)
+            if (g->hWu.rowptr[i + 1] - g->hWu.rowptr[i] != 4 || g->hWd.rowptr[i + 1] - g->hWd.rowptr[i] != 5) lds.uniform45 = 0;
         // register budget: the kernel is compiled for the smallest workgroup-size class that holds the block
         lds.maxt = (best == 12 && lds.block <= 640) ? 640 : 1024;
         if (lds.sb && !((best == 12 && lds.maxt == 640) || best == 8)) lds.sb = 0;
@@ -1326,7 +1330,7 @@ struct Engine : EngineBase {
 
     int launch_lds(const LdsArgs& a, int B) {
         const bool timed = prof_open(0, 0.0);
-        LdsLaunch L{lds.TPG, lds.maxt, lds.sb, lds.block, lds.lds_bytes};
+        LdsLaunch L{lds.TPG, lds.maxt, lds.sb, lds.uniform45, lds.block, lds.lds_bytes};
         const int rc = mg_lds_iteration(L, a, B, st);
         if (timed) prof_close();
         return rc;

@@ -36,6 +36,7 @@ struct LdsLaunch {
     int tpg;        // time steps per thread
     int maxt;       // workgroup-size class the kernel was compiled for (640 / 1024)
     int sb;         // single LDS vector (two workgroups per CU with the 640-thread class)
+    int uniform45;  // every W_u row has 4 and every W_d row 5 entries (k = 4 table without pads): unrolled gathers
     int block;      // threads per workgroup
     size_t lds_bytes;
 };

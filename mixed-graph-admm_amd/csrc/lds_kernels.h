@@ -119,7 +119,7 @@ __device__ __forceinline__ void lds_store(float* p, const float (&v)[TPG]) {
 //   slots so that rows start on all banks) -> the TPG time steps of any node are one contiguous, aligned
 //   run (vector ds_read), also for a gathered neighbour;
 //   HBM state is the reference's (T, N) order per sample: element (t, i) at t*N + i (coalesced over i).
-template <int TPG, bool BAND>
+template <int TPG, bool BAND, int NU = 0, int ND = 0>
 struct LdsCtx {
     int T, TS, N, t0, i;
     bool active;
@@ -170,6 +170,36 @@ struct LdsCtx {
             for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
         }
     }
+    // The same for a matrix whose rows all hold exactly NFIX entries (W_u: k, W_d: k + 1 of a kNN table without pads):
+    // straight-line code, every entry of the row is read up front, no per-lane trip count -- the divergent loop above
+    // costs an exec-mask region and a register copy per accumulator and trip.
+    template <int NFIX>
+    __device__ __forceinline__ void gather_fixed(const float* SRC, const int2* EN, int e0, float (&acc)[TPG]) const {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
+        const float* base = SRC + t0;
+        int2 en[NFIX];
+#pragma unroll
+        for (int u = 0; u < NFIX; ++u) en[u] = EN[e0 + u];
+#pragma unroll
+        for (int u = 0; u + 1 < NFIX; u += 2) {
+            float va[TPG], vb[TPG];
+            lds_load<TPG>(base + en[u].x, va);
+            lds_load<TPG>(base + en[u + 1].x, vb);
+            const float wa = __int_as_float(en[u].y), wb = __int_as_float(en[u + 1].y);
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) acc[k] += wb * vb[k];
+        }
+        if (NFIX & 1) {
+            float va[TPG];
+            lds_load<TPG>(base + en[NFIX - 1].x, va);
+            const float wa = __int_as_float(en[NFIX - 1].y);
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
+        }
+    }
     // band (line-graph) stencils on the node's own time row
     __device__ __forceinline__ void band_back(const float* SRC, float (&acc)[TPG]) const {
         const float* row = SRC + i * TS;
@@ -200,15 +230,17 @@ struct LdsCtx {
     // l = Lu(src): neighbours from SRC (LDS), the thread's own elements of src from registers (self)     ADMM.py:138-148
     __device__ __forceinline__ void op_lu(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
         float acc[TPG];
-        gather(SRC, en_u, u0, u1, acc);
+        if constexpr (NU > 0) gather_fixed<NU>(SRC, en_u, u0, acc);
+        else gather(SRC, en_u, u0, u1, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = self[k] - acc[k];
     }
     // l = Ldr(src)      ADMM.py:150-177
     __device__ __forceinline__ void op_ldr(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
         float acc[TPG];
-        if constexpr (!BAND) gather(SRC, en_d, d0, d1, acc);       // SRC: image stored with put<-1>
-        else band_back(SRC, acc);
+        if constexpr (BAND) band_back(SRC, acc);
+        else if constexpr (ND > 0) gather_fixed<ND>(SRC, en_d, d0, acc);       // SRC: image stored with put<-1>
+        else gather(SRC, en_d, d0, d1, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((k >= 1 || t0 >= 1) ? self[k] : 0.f) - acc[k];
     }
@@ -252,8 +284,8 @@ struct LdsCtx {
 // dc = diagonal coefficient of the own elements (H^T H or mask value, plus the rho/2 terms), see lds_diag.
 // Returns sum_k v_k * (A v)_k of the own elements.  Uses ctx.Q as scratch; contains a barrier for KIND 1.
 // Callers separate successive calls by barriers.
-template <int TPG, bool BAND, int KIND, bool SB>
-__device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND>& c, const float (&v)[TPG], float (&av)[TPG], const float (&dc)[TPG],
+template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND>
+__device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, const float (&v)[TPG], float (&av)[TPG], const float (&dc)[TPG],
                                            float c2) {
     float l[TPG];
 #pragma unroll
@@ -280,8 +312,8 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND>& c, const flo
 }
 // diagonal coefficient d + c1 of the own elements: d = dg[el] when dg != nullptr (mask values, global
 // memory), else [hth && t < t_in]   (ADMM.py:371-379: H^T H x resp. mask * x; ADMM.py:381-399: none)
-template <int TPG, bool BAND>
-__device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND>& c, const float* dg, int hth, int t_in, float c1, float (&dc)[TPG]) {
+template <int TPG, bool BAND, int NU, int ND>
+__device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND, NU, ND>& c, const float* dg, int hth, int t_in, float c1, float (&dc)[TPG]) {
 #pragma unroll
     for (int k = 0; k < TPG; ++k) {
         const float d = dg ? (c.active ? dg[c.gl(k)] : 0.f) : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
@@ -293,17 +325,17 @@ __device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND>& c, const float
 // p in registers with a copy in LDS (ctx.P) for the neighbours' gathers, A p in registers.  x holds x0 on entry and the solution on exit.  dmask: diagonal
 // of the initial residual when a mask is given (global memory); the iterations always use [t<t_in]
 // (quirk Q2).  Returns the iteration count (k+1) or -1.  Entry requirement: no thread still reads P/Q.
-template <int TPG, bool BAND, int KIND, bool SB>
-__device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
+template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND>
+__device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
                       int hth, int t_in, float c1, float c2, int max_cg, double tol, float* ah, float* bh, int Bp,
                       int* nonfinite) {
     constexpr int SHP = KIND == 1 ? -1 : 0;     // the image of the CG direction: read by Ldr (cLdr solves) or by Lu
     float r[TPG], pv[TPG], av[TPG], dc[TPG];
     c.template put<SHP>(c.P, x);
     __syncthreads();
-    lds_diag<TPG, BAND>(c, dmask, hth, t_in, c1, dc);
-    (void)lds_apply<TPG, BAND, KIND, SB>(c, x, av, dc, c2);
-    if (dmask != nullptr) lds_diag<TPG, BAND>(c, nullptr, hth, t_in, c1, dc);     // quirk Q2: iterations use [t < t_in]
+    lds_diag<TPG, BAND, NU, ND>(c, dmask, hth, t_in, c1, dc);
+    (void)lds_apply<TPG, BAND, KIND, SB, NU, ND>(c, x, av, dc, c2);
+    if (dmask != nullptr) lds_diag<TPG, BAND, NU, ND>(c, nullptr, hth, t_in, c1, dc);     // quirk Q2: iterations use [t < t_in]
     float part = 0.f;
 #pragma unroll
     for (int k = 0; k < TPG; ++k) {
@@ -316,7 +348,7 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, 
     int iters = -1;
     for (int it = 0; it < max_cg; ++it) {
         __syncthreads();                 // p complete in LDS
-        part = lds_apply<TPG, BAND, KIND, SB>(c, pv, av, dc, c2);
+        part = lds_apply<TPG, BAND, KIND, SB, NU, ND>(c, pv, av, dc, c2);
         const float pAp = br.sumf(part);         // barrier: every gather from P/Q of this iteration is done
         const float alpha = rr / pAp;
         part = 0.f;
@@ -351,7 +383,8 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND>& c, BlockRed& br, 
 // MAXT: workgroup-size class the kernel is compiled for (register budget).  SB: single LDS vector (q = Ldr p replaces p
 // in place, one more barrier per cLdr application); with the 640-thread class it is compiled for TWO resident
 // workgroups per CU (5 waves per SIMD, <= 96 VGPRs): two samples in flight per CU overlap each other's barriers.
-template <int TPG, bool BAND, int MAXT, bool SB>
+// NU / ND > 0: every row of W_u / W_d holds exactly that many entries (a kNN table without pads): unrolled gathers.
+template <int TPG, bool BAND, int MAXT, bool SB, int NU = 0, int ND = 0>
 __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(LdsArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     float* P = reinterpret_cast<float*>(lds_raw);
@@ -364,7 +397,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     for (int k = tid; k < a.csr_ints; k += blockDim.x) csr[k] = a.csr[k];
     if (tid < 32) red[tid] = 0.f;          // slots of non-existent waves must read as 0
 
-    LdsCtx<TPG, BAND> c;
+    LdsCtx<TPG, BAND, NU, ND> c;
     c.T = a.T; c.TS = a.TS; c.N = a.N;
     c.active = tid < a.nthreads;
     const int g = c.active ? tid / a.N : 0;
@@ -451,8 +484,8 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
 
     // ---- x solve (ADMM.py:571)
     int itx;
-    if (a.lhsx_kind == 1) itx = lds_cg<TPG, BAND, 1, SB>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, a.cx2, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
-    else itx = lds_cg<TPG, BAND, 0, SB>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, 0.f, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
+    if (a.lhsx_kind == 1) itx = lds_cg<TPG, BAND, 1, SB, NU, ND>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, a.cx2, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
+    else itx = lds_cg<TPG, BAND, 0, SB, NU, ND>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, 0.f, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
     c.putg(xn, x);
 
     // ---- batch 2: operands of the x metrics and of the zu solve
@@ -495,7 +528,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     }
 
     // ---- zu solve + gamma_u update (ADMM.py:579-580, 595)
-    int itzu = lds_cg<TPG, BAND, 2, SB>(c, br, z, rhs, nullptr, 0, 0, a.rho_u / 2.f, a.mu_u, a.max_cg, a.cg_tol, ah ? ah + hstride : nullptr,
+    int itzu = lds_cg<TPG, BAND, 2, SB, NU, ND>(c, br, z, rhs, nullptr, 0, 0, a.rho_u / 2.f, a.mu_u, a.max_cg, a.cg_tol, ah ? ah + hstride : nullptr,
                                         bh ? bh + hstride : nullptr, a.Bp, a.nonfinite);
     // ---- batch 3: x_new, old zu, gamma_u for the update + the operands of the next phase (zd solve, or the phi prox)
     float xr[TPG], zn[TPG], gn[TPG];
@@ -536,7 +569,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
             z[k] = zn[k];
             rhs[k] = c.active ? gn[k] / 2.f + a.rho_d / 2.f * xr[k] : 0.f;
         }
-        itzd = lds_cg<TPG, BAND, 1, SB>(c, br, z, rhs, nullptr, 0, 0, a.rho_d / 2.f, a.mu_d2, a.max_cg, a.cg_tol,
+        itzd = lds_cg<TPG, BAND, 1, SB, NU, ND>(c, br, z, rhs, nullptr, 0, 0, a.rho_d / 2.f, a.mu_d2, a.max_cg, a.cg_tol,
                               ah ? ah + 2 * hstride : nullptr, bh ? bh + 2 * hstride : nullptr, a.Bp, a.nonfinite);
         // ---- batch 4: x_new, old zd, gamma_d + the operands of the phi prox
         float zo[TPG], gv[TPG];

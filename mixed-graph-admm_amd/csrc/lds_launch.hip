@@ -21,9 +21,9 @@ int allow_lds(const void* fn, int bytes) {
     return MGADMM_OK;
 }
 
-template <int TPG, bool BAND, int MAXT, bool SB>
+template <int TPG, bool BAND, int MAXT, bool SB, int NU = 0, int ND = 0>
 int launch(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st) {
-    auto fn = k_admm_lds<TPG, BAND, MAXT, SB>;
+    auto fn = k_admm_lds<TPG, BAND, MAXT, SB, NU, ND>;
     MG_TRY(allow_lds((const void*)fn, 160 * 1024));
     hipLaunchKernelGGL(fn, dim3(B), dim3(L.block), L.lds_bytes, st, a);
     MG_HIP(hipGetLastError());
@@ -51,7 +51,9 @@ int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st
         case 3: return launch_b<3, 1024, false>(L, a, B, st);
         case 4: return launch_b<4, 1024, false>(L, a, B, st);
         case 6: return launch_b<6, 1024, false>(L, a, B, st);
-        case 8: return launch_b<8, 1024, false>(L, a, B, st);
+        case 8:
+            if (L.uniform45 && !a.band) return launch<8, false, 1024, false, 4, 5>(L, a, B, st);
+            return launch_b<8, 1024, false>(L, a, B, st);
         case 12: return launch_b<12, 1024, false>(L, a, B, st);
     }
     mg_set_error("lds: no kernel for TPG %d", L.tpg);
