@@ -1309,11 +1309,81 @@ struct Engine : EngineBase {
         lds.maxt = (best == 12 && lds.block <= 640) ? 640 : 1024;
         if (lds.sb && !((best == 12 && lds.maxt == 640) || best == 8)) lds.sb = 0;
         std::vector<int> img(off, 0);
+        // Bank-aware entry order.  A gather instruction reads entry e of 64 consecutive threads' rows (64 consecutive
+        // nodes, mostly); ds_read_b128 serves it in four groups of 16 lanes, and two lanes of a group collide when their
+        // neighbour rows start in the same 16-byte slot of the 256-byte bank line: slot = (TS/4 * col + const) mod 16,
+        // i.e. when col_a = col_b mod 16 for different columns (TS/4 is odd).  WHICH neighbour sits in entry e of a row is
+        // free: rows are taken in node order and every row picks the permutation of its entries that collides least with
+        // the rows already placed in its lane groups (all permutations up to 5 entries, the offset-sorted order and random
+        // shuffles beyond).  Round 1 kept the table order: 36 % of the LDS cycles of k_admm_lds were bank conflicts.
+        // The sum of a row then runs in the chosen order (fixed per graph: bitwise repeatable).
+        const bool bank_order = !band && best % 4 == 0 && ((lds.TS / 4) & 1) && !getenv("MGADMM_LDS_TABLE_ORDER");
+        auto slot_order = [&](const HostCsr& h) {
+            std::vector<int> order(h.nnz());
+            for (int e = 0; e < h.nnz(); ++e) order[e] = e;
+            if (!bank_order) return order;
+            static const int grp_of_lane[32] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
+            const int G = T / best;
+            int maxlen = 0;
+            for (int i = 0; i < N; ++i) maxlen = std::max(maxlen, h.rowptr[i + 1] - h.rowptr[i]);
+            const int nwaves = (N * G + 63) / 64;
+            // used[(wave*4 + group)*maxlen + e][colour] = column that occupies the colour (-1 free, -2 several)
+            std::vector<int> used((size_t)nwaves * 4 * maxlen * 16, -1);
+            unsigned rng = 12345u;
+            auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
+            for (int i = 0; i < N; ++i) {
+                const int e0 = h.rowptr[i], len = h.rowptr[i + 1] - e0;
+                if (len <= 1) continue;
+                int keys[16];                                       // lane groups this node's threads (one per time group) sit in
+                for (int gq = 0; gq < G; ++gq) {
+                    const int tid = i + N * gq, lane = tid & 63;
+                    keys[gq] = (tid >> 6) * 4 + (lane >> 5) * 2 + grp_of_lane[lane & 31];
+                }
+                auto cost = [&](const std::vector<int>& perm) {
+                    int c = 0;
+                    for (int e = 0; e < len; ++e) {
+                        const int col = h.col[e0 + perm[e]], colour = col & 15;
+                        for (int gq = 0; gq < G; ++gq) {
+                            const int u = used[((size_t)keys[gq] * maxlen + e) * 16 + colour];
+                            if (u != -1 && u != col) ++c;
+                        }
+                    }
+                    return c;
+                };
+                std::vector<int> perm(len), bestp;
+                for (int e = 0; e < len; ++e) perm[e] = e;
+                int bc = 1 << 30;
+                if (len <= 5) {
+                    do {
+                        const int c = cost(perm);
+                        if (c < bc) { bc = c; bestp = perm; }
+                    } while (bc > 0 && std::next_permutation(perm.begin(), perm.end()));
+                } else {
+                    std::vector<int> p2 = perm;
+                    std::stable_sort(p2.begin(), p2.end(), [&](int a, int b) { return h.col[e0 + a] - i < h.col[e0 + b] - i; });
+                    for (int trial = 0; trial < 300 && bc > 0; ++trial) {
+                        const int c = cost(p2);
+                        if (c < bc) { bc = c; bestp = p2; }
+                        for (int e = len - 1; e > 0; --e) std::swap(p2[e], p2[rnd() % (e + 1)]);
+                    }
+                }
+                for (int e = 0; e < len; ++e) {
+                    order[e0 + e] = e0 + bestp[e];
+                    const int col = h.col[e0 + bestp[e]], colour = col & 15;
+                    for (int gq = 0; gq < G; ++gq) {
+                        int& u = used[((size_t)keys[gq] * maxlen + e) * 16 + colour];
+                        u = (u == -1 || u == col) ? col : -2;
+                    }
+                }
+            }
+            return order;
+        };
         auto put_csr = [&](const HostCsr& h, int off_rp, int off_en) {
+            const std::vector<int> order = slot_order(h);
             for (int i = 0; i <= N; ++i) img[off_rp + i] = h.rowptr[i];
             for (int e = 0; e < h.nnz(); ++e) {
-                img[off_en + 2 * e] = h.col[e] * lds.TS;       // LDS float offset of the neighbour's time row
-                memcpy(&img[off_en + 2 * e + 1], &h.val[e], 4);
+                img[off_en + 2 * e] = h.col[order[e]] * lds.TS;       // LDS float offset of the neighbour's time row
+                memcpy(&img[off_en + 2 * e + 1], &h.val[order[e]], 4);
             }
         };
         put_csr(g->hWu, lds.off_rp_u, lds.off_en_u);
