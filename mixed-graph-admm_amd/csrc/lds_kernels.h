@@ -261,8 +261,17 @@ struct LdsCtx {
             lds_store<TPG>(DST + own(), v);
         } else {
             float* row = DST + i * TS + t0 - SH;            // index of element k = 0
+            // the 16-byte groups of the image that lie entirely inside this thread's elements go out as one aligned
+            // ds_write_b128 each (SH = -1: v[3..6], v[7..10], ...; SH = +1: v[1..4], v[5..8], ...); the elements at the two
+            // ends are scalar stores (rows are 16-byte aligned, so scalar stores of 32 consecutive nodes hit 8 banks: 4-way)
+            constexpr int K0 = SH < 0 ? 3 : 1;              // first element of the first whole group
+            constexpr int NG = TPG % 4 == 0 ? (TPG - K0) / 4 : 0;
+#pragma unroll
+            for (int j = 0; j < NG; ++j)
+                reinterpret_cast<float4*>(row + K0 + 4 * j)[0] = make_float4(v[K0 + 4 * j], v[K0 + 4 * j + 1], v[K0 + 4 * j + 2], v[K0 + 4 * j + 3]);
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
+                if (k >= K0 && k < K0 + 4 * NG) continue;
                 const bool ok = SH < 0 ? (k < TPG - 1 || t0 + TPG < T) : (k > 0 || t0 > 0);   // index T resp. -1 does not exist
                 if (ok) row[k] = v[k];
             }
