@@ -62,6 +62,9 @@ struct BlockRed {
     // (all four rows compute the same sum in the same order); lane 15's value is broadcast.  8 VALU + 1 ds_read
     // instead of 15 VALU + 4 ds_read_b128 + two float<->double conversions per reduction.
     __device__ __forceinline__ float sumf(float v) {
+#ifdef MGADMM_KO_NORED           // knock-out timing build: no workgroup reduction (and none of its barriers)
+        return v + 1.0f;
+#endif
         v = wave_sum(v);
         float* buf = red + par * 16;
         if (lane == 0) buf[wave] = v;
@@ -146,6 +149,9 @@ struct LdsCtx {
     __device__ __forceinline__ void gather(const float* SRC, const int2* EN, int e0, int e1, float (&acc)[TPG]) const {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
+#ifdef MGADMM_KO_NOGATHER        // knock-out timing build (make EXTRA=-DMGADMM_KO_...): everything but the LDS gathers
+        return;
+#endif
         const float* base = SRC + t0;
         int2 na = EN[e0], nb = EN[e0 + 1];          // the arrays are padded by 3 entries: reads past e1 are safe
         int e = e0;
@@ -177,6 +183,9 @@ struct LdsCtx {
     __device__ __forceinline__ void gather_fixed(const float* SRC, const int2* EN, int e0, float (&acc)[TPG]) const {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
+#ifdef MGADMM_KO_NOGATHER
+        return;
+#endif
         const float* base = SRC + t0;
         int2 en[NFIX];
 #pragma unroll
@@ -359,7 +368,11 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
         __syncthreads();                 // p complete in LDS
         part = lds_apply<TPG, BAND, KIND, SB, NU, ND>(c, pv, av, dc, c2);
         const float pAp = br.sumf(part);         // barrier: every gather from P/Q of this iteration is done
+#ifdef MGADMM_KO_FIXED           // knock-out timing builds run a fixed number of iterations on made-up coefficients
+        const float alpha = 1e-3f + 0.f * pAp;
+#else
         const float alpha = rr / pAp;
+#endif
         part = 0.f;
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
@@ -368,12 +381,22 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
             part += r[k] * r[k];
         }
         const float rrn = br.sumf(part);
+#ifdef MGADMM_KO_FIXED
+        const float beta = 0.5f + 0.f * rrn;
+#else
         const float beta = rrn / rr;
+#endif
         rr = rrn;
         if (ah != nullptr && threadIdx.x == 0) {
             ah[(size_t)it * Bp] = alpha;
             bh[(size_t)it * Bp] = beta;
         }
+#ifdef MGADMM_KO_FIXED
+#ifndef MGADMM_KO_ITERS
+#define MGADMM_KO_ITERS 0
+#endif
+        if (it + 1 == (MGADMM_KO_ITERS ? MGADMM_KO_ITERS : (KIND == 2 ? 11 : 17))) { iters = it + 1; break; }
+#else
         if (!(fabsf(rrn) <= 3.0e38f)) {       // NaN / Inf: report and stop this sample
             if (threadIdx.x == 0) *nonfinite = 1;
             break;
@@ -382,6 +405,7 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
             iters = it + 1;
             break;
         }
+#endif
 #pragma unroll
         for (int k = 0; k < TPG; ++k) pv[k] = r[k] + beta * pv[k];
         c.template put<SHP>(c.P, pv);
