@@ -71,6 +71,7 @@ struct Engine : EngineBase {
     } cldr_dev;
     int use_fused = 1;            // MGADMM_FUSED=0 keeps the two-pass cLdr (tests compare the two)
     int use_fold = 1;             // MGADMM_FOLD=0: p = r + beta p and x += alpha p stay in their own kernel (EpiPUpdate)
+    int sweep_rev = 1;            // MGADMM_SWEEP_REV=0: r -= alpha Ap sweeps the time slices upwards like every other kernel
     int cldr_tile_major = 1;      // MGADMM_CLDR_ORDER=0: chunks of a tile adjacent in dispatch order
     int cur_P = 0;                // partial rows written by the last row-kernel launch (k_rows or k_tile)
     int use_tile = 1;             // LDS-tiled spatial kernel on cluster-ordered graphs (reorder = 2); MGADMM_TILE=0 disables
@@ -142,6 +143,7 @@ struct Engine : EngineBase {
         q.NX = q.NBL * ri;
         q.n_items = T * q.NBL;
         q.grid = q.P * q.CH;
+        q.rev = 0;
         return q;
     }
 
@@ -401,6 +403,7 @@ struct Engine : EngineBase {
         if (const char* e = getenv("MGADMM_TILE")) use_tile = atoi(e);
         if (const char* e = getenv("MGADMM_FUSED")) use_fused = atoi(e);
         if (const char* e = getenv("MGADMM_FOLD")) use_fold = atoi(e);
+        if (const char* e = getenv("MGADMM_SWEEP_REV")) sweep_rev = atoi(e);
         if (const char* e = getenv("MGADMM_CLDR_ORDER")) cldr_tile_major = atoi(e);
         Geom q = make_geom(Bmax);
         Bp_max = q.Bp;
@@ -805,7 +808,13 @@ struct Engine : EngineBase {
                 MG_TRY(lhs_apply(q, d, pp, nullptr, Ap, live));                  // Ap = A p (no mask: quirk Q2)
             }
             MG_TRY((reduce<1>(q, FinCgAlpha<S>{c, k, q.Bp}, live)));
-            MG_TRY(rows<EpiCgUpdate>(q, op_none(), Ap, live, 1, 3, (const S*)d_alpha, r));                 // r -= alpha Ap, r.r
+            {
+                // r -= alpha Ap, r.r -- swept from the LAST time slice down: the SpMM kernel before it finished with the
+                // last slices of Ap (still in the Infinity Cache), and the kernel after it starts with the first slices of r
+                Geom qr = q;
+                qr.rev = sweep_rev;
+                MG_TRY(rows<EpiCgUpdate>(qr, op_none(), Ap, live, 1, 3, (const S*)d_alpha, r));
+            }
             MG_TRY((reduce<1>(q, FinCgBeta<S>{c, k, q.Bp, p.cg_tol, batch_max}, live)));
             if (!fold)
                 MG_TRY(rows<EpiPUpdate>(q, op_none(), r, live, 1, 5, (const S*)d_alpha, (const S*)d_beta, xout, pp));   // x += alpha p, p = r + beta p

@@ -57,6 +57,8 @@ struct Geom {
     int G8;              // workgroups per (XCD, column chunk)
     int P;               // partial-sum rows per column = 8 * G8 (one per workgroup of a chunk)
     int grid;            // 8 * G8 * CH workgroups
+    int rev;             // 1: sweep the time slices from T-1 down to 0 (see Engine::cg_internal: the slices a kernel touches
+                         //    LAST are the ones still in the 256 MiB Infinity Cache when the next kernel starts)
 };
 
 constexpr int CSR_PAD = 8;     // col/val arrays carry this many extra entries (reads past a row end are safe)
@@ -178,8 +180,9 @@ __global__ __launch_bounds__(256) void k_rows(Geom g, OpDesc op, const int* __re
     const bool spatial = op.kind == OPK_SPATIAL;
     const int xlo = xcd * g.NX, xhi = min(g.N, xlo + g.NX);   // node rows this XCD owns, for every time slice
     for (int item = r; item < g.n_items; item += g.G8) {
-        const int t = item / g.NBL;
-        const int nb = item - t * g.NBL;
+        const int tq = item / g.NBL;
+        const int nb = item - tq * g.NBL;
+        const int t = g.rev ? g.T - 1 - tq : tq;
         const int n0 = xlo + nb * g.RI;
         const int n1 = min(xhi, n0 + g.RI);
         int i = n0 + wave;

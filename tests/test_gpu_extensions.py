@@ -165,3 +165,28 @@ def test_resume_equals_uninterrupted_solve(path, abl, task):
     with pytest.raises(ValueError, match="warm_start misses"):
         blk.solve(yt, mask=mt, warm_start={"x": saved["x"]})
     blk.close()
+
+
+def test_resume_on_the_fused_streaming_path_with_the_folded_vector_update():
+    """The same resume property at B = 256 with the cluster order: the x / zd solves run through k_cldr with the CG vector
+    update folded into its loads (p alternates between two buffers, the last x update is applied after the loop)."""
+    import helpers
+    g = load_golden("g4_meta.npz")
+    rng = np.random.default_rng(11)
+    yt = torch.from_numpy((100 + 50 * rng.random((256, 12, 30, 1))).astype(np.float32))
+    blk = helpers.make_product(g, "knn", path="stream", reorder="cluster")
+    blk.check_stop = False
+    blk.max_ADMM_iter = 5
+    x_full = blk.solve(yt)[0]
+    full = np.array(blk.p_res_list)
+    blk._reset_history()
+    blk.max_ADMM_iter = 2
+    blk.solve(yt)
+    saved = {k: v.clone() for k, v in blk.state.items()}
+    first = np.array(blk.p_res_list)
+    blk._reset_history()
+    blk.max_ADMM_iter = 3
+    x_res = blk.solve(yt, warm_start=saved)[0]
+    assert torch.equal(x_res, x_full)
+    np.testing.assert_array_equal(np.concatenate([first, np.array(blk.p_res_list)]), full)
+    blk.close()
