@@ -43,6 +43,7 @@ struct Engine : EngineBase {
 
     S* vec[V_COUNT] = {nullptr};
     S* vec_pool = nullptr;
+    int dev_cus = 0;               // compute units of the device (staggered start of k_admm_lds)
     size_t vec_elems = 0;
     S* partials = nullptr;
     size_t partials_elems = 0;
@@ -1271,6 +1272,7 @@ struct Engine : EngineBase {
     // ---------------------------------------------------------------- LDS-resident fused path
     int plan_lds() {
         lds = LdsPlan();
+        if (hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, g->device) != hipSuccess) { (void)hipGetLastError(); dev_cus = 0; }
         if (!std::is_same<S, float>::value) return MGADMM_OK;
         const int tpgs[] = {1, 2, 3, 4, 6, 8, 12};
         int best = 0;
@@ -1476,6 +1478,14 @@ struct Engine : EngineBase {
             a.off_en_u = lds.off_en_u; a.off_en_d = lds.off_en_d; a.off_en_t = lds.off_en_t;
             a.band_w = g->band_w;
             a.zu = zu; a.zd = zd; a.phi = phi; a.gam = gam; a.gu = gu; a.gd = gd;
+            // staggered start (k_admm_lds): only when the launch runs several rounds of workgroups per CU
+            {
+                const int ncu = dev_cus > 0 ? dev_cus : 256;
+                int us = 48;
+                if (const char* e = getenv("MGADMM_LDS_STAGGER_US")) us = atoi(e);
+                a.stagger_wgs = ncu;
+                a.stagger_ticks = (B >= 2 * ncu && us > 0) ? us * 100 : 0;
+            }
             a.y = (const float*)y; a.mask = (const float*)mask;
             a.ps = d_ps; a.alpha_hist = record ? (float*)d_alpha_hist : nullptr; a.beta_hist = record ? (float*)d_beta_hist : nullptr;
             a.nonfinite = d_nonfinite;

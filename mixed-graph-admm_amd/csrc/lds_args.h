@@ -10,6 +10,7 @@ struct LdsArgs {
     int band, skip, q1;
     int max_cg;
     int record;            // alpha/beta history
+    int stagger_wgs, stagger_ticks;   // the first `stagger_wgs` workgroups start up to `stagger_ticks` (10 ns) late, see k_admm_lds
     float rho, rho_u, rho_d, mu_u, mu_d1, mu_d2;
     float cx1, cx2;        // LHS_x = HtH + cx1*I + cx2*cLdr
     double cg_tol;

@@ -20,6 +20,7 @@
 #include "lds_args.h"
 
 
+
 // wave64 sum with DPP row shifts / row broadcasts (no LDS traffic); the total ends up in lane 63 and is
 // broadcast with readlane.  Fixed association order -> bitwise repeatable.
 template <int CTRL, int ROW_MASK>
@@ -117,6 +118,14 @@ __device__ __forceinline__ void lds_store(float* p, const float (&v)[TPG]) {
     }
 }
 
+// Global load as uniform base + 32-bit unsigned byte offset: the SGPR-base form of global_load (one offset VGPR shared by
+// every vector of a request) instead of a 64-bit address pair per access.
+__device__ __forceinline__ float ldg(const float* base, unsigned boff) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
+}
+// REQUEST fence: the loads before it are issued together and waited for together, nothing crosses it.
+#define MG_REQ_FENCE() asm volatile("" ::: "memory")
+
 // Per-thread view: node i, time steps t0 .. t0+TPG-1.
 //   LDS vectors are node-major, time innermost: A[node*TS + t] (row stride TS >= T, an odd number of 16-B
 //   slots so that rows start on all banks) -> the TPG time steps of any node are one contiguous, aligned
@@ -134,6 +143,7 @@ struct LdsCtx {
     const float* band_w;
 
     __device__ __forceinline__ int gl(int k) const { return (t0 + k) * N + i; }   // HBM index
+    __device__ __forceinline__ unsigned glb(int k) const { return 4u * (unsigned)((t0 + k) * N + i); }   // ... as a byte offset
     __device__ __forceinline__ int own() const { return i * TS + t0; }            // LDS index of element k = 0
 
     // SHIFTED LDS IMAGES.  A vector that is only gathered through a time-shifted operator is stored shifted: the image
@@ -427,9 +437,37 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     int* csr = reinterpret_cast<int*>(red + 32);
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
-    for (int k = tid; k < a.csr_ints; k += blockDim.x) csr[k] = a.csr[k];
-    if (tid < 32) red[tid] = 0.f;          // slots of non-existent waves must read as 0
-
+    // diagnostic build (make EXTRA=-DMGADMM_PHASE_CLOCK): the per-sample metric slots receive the 100 MHz clock at the
+    // phase boundaries instead of the metrics (tools/lds_phase_clock.py)
+    auto stamp = [&](int m) {
+#ifdef MGADMM_PHASE_CLOCK
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long tck = wall_clock64();
+        if (tid == 0) a.ps[(size_t)m * a.Bp + b] = (double)tck;
+#endif
+    };
+    // MGADMM_PHASE_CLOCK=2: slots 8..10 split the "batch 1 + RHS_x" phase instead of timing the last three phases
+    auto stamp_late = [&](int m) {
+#if defined(MGADMM_PHASE_CLOCK) && MGADMM_PHASE_CLOCK == 1
+        stamp(m);
+#endif
+    };
+    auto stamp_rhs = [&](int m) {
+#if defined(MGADMM_PHASE_CLOCK) && MGADMM_PHASE_CLOCK == 2
+        stamp(m);
+#endif
+    };
+    // STAGGERED START.  Samples of one batch need (nearly) the same CG iteration counts, so the workgroups of a launch
+    // run in lock step: all CUs store their results and request the next sample's operands at the same moment, while HBM
+    // idles during the CG solves.  The workgroups of the first round (one per CU) start spread over `stagger_ticks`,
+    // their successors inherit the offset: the operand requests of different CUs no longer coincide (cfg2: 48 us of
+    // spread, -1.3 % per launch although the launch itself gets 48 us longer).
+    if (a.stagger_ticks > 0 && b < a.stagger_wgs) {
+        const unsigned long long wait = (unsigned long long)a.stagger_ticks * (unsigned)b / (unsigned)a.stagger_wgs;
+        const unsigned long long t_in0 = wall_clock64();
+        while (wall_clock64() - t_in0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+    stamp(0);
     LdsCtx<TPG, BAND, NU, ND> c;
     c.T = a.T; c.TS = a.TS; c.N = a.N;
     c.active = tid < a.nthreads;
@@ -441,7 +479,80 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     c.en_u = reinterpret_cast<const int2*>(csr + a.off_en_u);
     c.en_d = reinterpret_cast<const int2*>(csr + a.off_en_d);
     c.en_t = reinterpret_cast<const int2*>(csr + a.off_en_t);
+
+    const size_t sb = (size_t)b * a.TN;
+    const float* xo = a.x_old + sb;
+    float* xn = a.x_new + sb;
+    float *zu = a.zu + sb, *zd = a.zd + sb, *phi = a.phi + sb, *gam = a.gam + sb, *gu = a.gu + sb, *gd = a.gd + sb;
+    const float* mk = a.mask ? a.mask + sb : nullptr;
+    const int ty = a.mask ? a.T : a.t_in;
+    const float* yb = a.y + (size_t)b * ty * a.N;
+
+    // REQUEST of two operand vectors (TPG elements each per thread): 2 * TPG unconditional loads issued together and
+    // waited for together; nothing crosses the fence, so the destination registers of one request are all a batch needs.
+    auto request2 = [&](const float* A, const float* B, const unsigned (&oa)[TPG], const unsigned (&ob)[TPG], float (&va)[TPG], float (&vb)[TPG]) {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) { va[k] = ldg(A, oa[k]); vb[k] = ldg(B, ob[k]); }
+        MG_REQ_FENCE();
+    };
+
+    // ---- batch 1: x_old and every operand of RHS_x (ADMM.py:556-564), requested FIRST, before the CSR image is copied:
+    // nothing else is live yet, so a request keeps its destination registers without spilling.
+    // The operands are read in REQUESTS of two vectors whose loads are unconditional and branch-free: an operand the
+    // ablation does not use is read through a pointer to a vector that exists, rows of y past t_in through a clamped
+    // index, idle threads read node 0, and the values are selected afterwards.  With the loads inside `if (flag)` regions
+    // (round 1 .. mid round 2) the compiler waited for every group of one or two loads: 40 dependent memory round trips,
+    // 19 us + 2 us for the CSR copy in the instrumented build (tools/lds_phase_clock.py), against 9 us for both now; a
+    // workgroup alone pulls the 221 KB in 6 us (tools/probe_batch_load.hip).  Production build: -1.9 % per launch.
+    float x[TPG], o[TPG], v[TPG];
+    {
+        const bool use_v = a.has_phi && !a.first;
+        const float* zdp = a.has_zd ? zd : zu;
+        const float* gdp = a.has_zd ? gd : gu;
+        const float* gamp = use_v ? gam : gu;
+        const float* phip = use_v ? phi : zu;
+        unsigned off[TPG], offy[TPG];
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            const int t = c.t0 + k;
+            off[k] = c.glb(k);
+            offy[k] = 4u * (unsigned)((t < ty ? t : ty - 1) * a.N + c.i);
+        }
+        float ta[TPG], tb[TPG];
+        request2(zu, zdp, off, off, ta, tb);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) o[k] = a.has_zd ? (a.rho_u * ta[k] + a.rho_d * tb[k]) / 2.f : a.rho_u * ta[k] / 2.f;
+        request2(gu, gdp, off, off, ta, tb);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) o[k] = o[k] - (a.has_zd ? (ta[k] + tb[k]) / 2.f : ta[k] / 2.f);
+        request2(yb, xo, offy, off, ta, tb);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            o[k] = c.active ? o[k] + ((c.t0 + k < ty) ? ta[k] : 0.f) : 0.f;
+            x[k] = c.active ? tb[k] : 0.f;
+        }
+        request2(gamp, phip, off, off, ta, tb);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) v[k] = (c.active && use_v) ? ta[k] + a.rho * tb[k] : 0.f;
+    }
+    stamp_rhs(8);
+    // CSR image -> LDS, eight words per thread in flight (one word per trip cost ten dependent L2 round trips, 3.6 us)
+    for (int k0 = tid; k0 < a.csr_ints; k0 += 8 * (int)blockDim.x) {
+        int wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u * (int)blockDim.x;
+            wv[u] = a.csr[k < a.csr_ints ? k : a.csr_ints - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + u * (int)blockDim.x;
+            if (k < a.csr_ints) csr[k] = wv[u];
+        }
+    }
+    if (tid < 32) red[tid] = 0.f;          // slots of non-existent waves must read as 0
     __syncthreads();
+    stamp(1);
     c.u0 = csr[a.off_rp_u + c.i]; c.u1 = csr[a.off_rp_u + c.i + 1];
     c.d0 = c.d1 = c.t0e = c.t1e = 0;
     if (!BAND) {
@@ -454,34 +565,13 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     // across the CG solves); the whole-batch values are formed by k_batch_metrics
     auto emit = [&](int m, double v, bool keep) {
         const double sres = br.sum((float)v);
+#ifdef MGADMM_PHASE_CLOCK
+        if (tid == 0 && sres == 123.456) a.ps[(size_t)m * a.Bp + b] = sres;
+#else
         if (tid == 0) a.ps[(size_t)m * a.Bp + b] = keep ? sres : 0.0;
+#endif
     };
 
-    const size_t sb = (size_t)b * a.TN;
-    const float* xo = a.x_old + sb;
-    float* xn = a.x_new + sb;
-    float *zu = a.zu + sb, *zd = a.zd + sb, *phi = a.phi + sb, *gam = a.gam + sb, *gu = a.gu + sb, *gd = a.gd + sb;
-    const float* mk = a.mask ? a.mask + sb : nullptr;
-    const int ty = a.mask ? a.T : a.t_in;
-    const float* yb = a.y + (size_t)b * ty * a.N;
-
-    // Global operands are requested in BATCHES ahead of the barriers that separate their uses (the compiler does not move
-    // loads across a barrier): one exposed HBM latency per phase boundary instead of one per operand group.
-    // ---- batch 1: x_old and every operand of RHS_x (ADMM.py:556-564)
-    float x[TPG], o[TPG], v[TPG];
-#pragma unroll
-    for (int k = 0; k < TPG; ++k) {
-        x[k] = o[k] = v[k] = 0.f;
-        if (c.active) {
-            const int e = c.gl(k);
-            const int t = c.t0 + k;
-            x[k] = xo[e];
-            const float yv = (t < ty) ? yb[t * a.N + c.i] : 0.f;
-            if (a.has_zd) o[k] = (a.rho_u * zu[e] + a.rho_d * zd[e]) / 2.f - (gu[e] + gd[e]) / 2.f + yv;
-            else o[k] = a.rho_u * zu[e] / 2.f - gu[e] / 2.f + yv;
-            if (a.has_phi && !a.first) v[k] = gam[e] + a.rho * phi[e];
-        }
-    }
     // ---- first iteration only: phi = Ldr x0 (ADMM.py:541); the dual variables were filled by k_init_lds
     if (a.has_phi && a.first) {
         float ph[TPG];
@@ -505,8 +595,10 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         if (a.has_phi) {
             c.template put<+1>(P, v);
             __syncthreads();
+            stamp_rhs(9);
             if (c.active) c.op_ldrt(P, v, l);
             __syncthreads();
+            stamp_rhs(10);
         }
 #pragma unroll
         for (int k = 0; k < TPG; ++k) rhs[k] = c.active ? (a.has_phi ? l[k] / 2.f + o[k] : o[k]) : 0.f;
@@ -515,10 +607,12 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     float* bh = a.record ? a.beta_hist + b : nullptr;
     const size_t hstride = (size_t)a.max_cg * a.Bp;
 
+    stamp(2);
     // ---- x solve (ADMM.py:571)
     int itx;
     if (a.lhsx_kind == 1) itx = lds_cg<TPG, BAND, 1, SB, NU, ND>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, a.cx2, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
     else itx = lds_cg<TPG, BAND, 0, SB, NU, ND>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, 0.f, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
+    stamp(3);
     c.putg(xn, x);
 
     // ---- batch 2: operands of the x metrics and of the zu solve
@@ -560,9 +654,11 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         emit(MGADMM_M_RECOVER, m_rec, true);
     }
 
+    stamp(4);
     // ---- zu solve + gamma_u update (ADMM.py:579-580, 595)
     int itzu = lds_cg<TPG, BAND, 2, SB, NU, ND>(c, br, z, rhs, nullptr, 0, 0, a.rho_u / 2.f, a.mu_u, a.max_cg, a.cg_tol, ah ? ah + hstride : nullptr,
                                         bh ? bh + hstride : nullptr, a.Bp, a.nonfinite);
+    stamp(5);
     // ---- batch 3: x_new, old zu, gamma_u for the update + the operands of the next phase (zd solve, or the phi prox)
     float xr[TPG], zn[TPG], gn[TPG];
     {
@@ -602,8 +698,10 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
             z[k] = zn[k];
             rhs[k] = c.active ? gn[k] / 2.f + a.rho_d / 2.f * xr[k] : 0.f;
         }
+        stamp(6);
         itzd = lds_cg<TPG, BAND, 1, SB, NU, ND>(c, br, z, rhs, nullptr, 0, 0, a.rho_d / 2.f, a.mu_d2, a.max_cg, a.cg_tol,
                               ah ? ah + 2 * hstride : nullptr, bh ? bh + 2 * hstride : nullptr, a.Bp, a.nonfinite);
+        stamp(7);
         // ---- batch 4: x_new, old zd, gamma_d + the operands of the phi prox
         float zo[TPG], gv[TPG];
 #pragma unroll
@@ -638,6 +736,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
 
     // ---- phi prox, gamma update, Ldr/Lu based diagnostics (ADMM.py:600-606, 619, 627-637); xr = x_new, zn = phi_old, gn = gamma
     double m_priphi = 0, m_dualphi = 0, m_dgtv = 0, m_dglr = 0, m_glr = 0;
+    stamp_late(8);
     __syncthreads();          // every LDS read of the last CG is done
     c.template put<-1>(P, xr);        // read by Ldr
     if (!SB) c.template put<0>(Q, xr);   // read by Lu (GLR); SB: Q aliases P, see below
@@ -681,11 +780,13 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         }
     }
 
+    stamp_late(9);
     emit(MGADMM_M_PRI_PHI, m_priphi, a.has_phi);
     emit(MGADMM_M_DUAL_PHI, m_dualphi, a.has_phi);
     emit(MGADMM_M_DGTV, m_dgtv, a.has_phi);
     emit(MGADMM_M_DGLR, m_dglr, a.has_zd);
     emit(MGADMM_M_GLR, m_glr, true);
+    stamp_late(10);
     if (tid == 0) {
         a.cg_iters[b] = itx;
         a.cg_iters[a.Bp + b] = itzu;

@@ -268,8 +268,10 @@ def check_solve(blk, key, G, abl, x, xtol, htol, it_slack):
     assert rel(x, G("x")) < xtol, key
     n = int(G("n_iters"))
     assert len(blk.p_res_list) == n
-    # residuals are norms of differences of O(|x|) numbers: absolute floor ~ eps * ||x|| (1e-8 ||x|| in f32)
-    floor = (1e-8 if htol >= 1e-4 else 1e-14) * float(np.linalg.norm(G("x")))
+    # residuals are norms of differences of O(|x|) numbers: every element of x - z carries a rounding error of eps |x_i|, so
+    # the norm has an absolute noise floor of eps ||x|| (float32: eps = 6e-8 -> 1e-7 ||x||, the floor of
+    # test_gpu_baseline_configs.py; float64: 1e-14 ||x||).  Entries of a nearly converged residual sit below it.
+    floor = (1e-7 if htol >= 1e-4 else 1e-14) * float(np.linalg.norm(G("x")))
     np.testing.assert_allclose(np.array(blk.p_res_list), G("p_res"), rtol=htol, atol=floor)
     np.testing.assert_allclose(np.array(blk.d_res_list), G("d_res"), rtol=htol, atol=floor)
     np.testing.assert_allclose(blk.x_shift_list, G("x_shift"), rtol=htol)
