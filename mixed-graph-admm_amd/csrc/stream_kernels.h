@@ -1271,9 +1271,19 @@ __global__ __launch_bounds__(1024) void k_reduce(const S* __restrict__ partials,
 #pragma unroll
             for (int r = 0; r < NRED; ++r) s[r] += (double)v[k][r];
     }
-    for (; p < P; p += 16) {
+    // the remaining rows (< RB per wave) in ONE more trip: rows past P are read at the last row and enter as 0
+    if (p < P) {
+        S v[RB][NRED];
 #pragma unroll
-        for (int r = 0; r < NRED; ++r) s[r] += (double)partials[((size_t)r * P + p) * Bp + c];
+        for (int k = 0; k < RB; ++k) {
+            const int row = p + 16 * k;
+#pragma unroll
+            for (int r = 0; r < NRED; ++r) v[k][r] = partials[((size_t)r * P + (row < P ? row : P - 1)) * Bp + c];
+        }
+#pragma unroll
+        for (int k = 0; k < RB; ++k)
+#pragma unroll
+            for (int r = 0; r < NRED; ++r) s[r] += (p + 16 * k < P) ? (double)v[k][r] : 0.0;
     }
     __shared__ double sm[15][NRED][64];
     if (wave > 0) {
