@@ -68,7 +68,7 @@ struct BlockRed {
 #endif
         v = wave_sum(v);
         float* buf = red + par * 16;
-        if (lane == 0) buf[wave] = v;
+        if (lane == 0) buf[wave] = v;      // (all 64 lanes storing the same word instead: +1.2 % per launch)
         __syncthreads();
         float t = buf[lane & 15];
         t = dpp_step<0x111, 0xf>(t);   // row_shr:1
@@ -108,7 +108,13 @@ template <int TPG>
 __device__ __forceinline__ void lds_store(float* p, const float (&v)[TPG]) {
     if constexpr (TPG % 4 == 0) {
 #pragma unroll
-        for (int j = 0; j < TPG / 4; ++j) reinterpret_cast<float4*>(p)[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+        for (int j = 0; j < TPG / 4; ++j) {
+            // native vector type + assume_aligned, as in lds_load: a struct float4 store is split into scalars and
+            // re-fused as ds_write2_b32 pairs
+            lds_f4 q;
+            q.x = v[4 * j]; q.y = v[4 * j + 1]; q.z = v[4 * j + 2]; q.w = v[4 * j + 3];
+            static_cast<lds_f4*>(__builtin_assume_aligned(p, 16))[j] = q;
+        }
     } else if constexpr (TPG % 2 == 0) {
 #pragma unroll
         for (int j = 0; j < TPG / 2; ++j) reinterpret_cast<float2*>(p)[j] = make_float2(v[2 * j], v[2 * j + 1]);
@@ -273,7 +279,9 @@ struct LdsCtx {
     }
     // own elements -> LDS image read by an operator that gathers time t + SH (SH = 0: Lu and the band stencils, -1: Ldr,
     // +1: Ldr^T): index j of a node's row holds time j + SH, 0 outside [0,T)
-    template <int SH>
+    // EDGE = false: the slot that holds time -1 resp. T (always 0) is left alone -- within one CG solve it is written
+    // once, with the first image, and no other store touches it
+    template <int SH, bool EDGE = true>
     __device__ __forceinline__ void put(float* DST, const float (&v)[TPG]) const {
         if (!active) return;
         if constexpr (SH == 0 || BAND) {
@@ -286,16 +294,21 @@ struct LdsCtx {
             constexpr int K0 = SH < 0 ? 3 : 1;              // first element of the first whole group
             constexpr int NG = TPG % 4 == 0 ? (TPG - K0) / 4 : 0;
 #pragma unroll
-            for (int j = 0; j < NG; ++j)
-                reinterpret_cast<float4*>(row + K0 + 4 * j)[0] = make_float4(v[K0 + 4 * j], v[K0 + 4 * j + 1], v[K0 + 4 * j + 2], v[K0 + 4 * j + 3]);
+            for (int j = 0; j < NG; ++j) {
+                lds_f4 q;
+                q.x = v[K0 + 4 * j]; q.y = v[K0 + 4 * j + 1]; q.z = v[K0 + 4 * j + 2]; q.w = v[K0 + 4 * j + 3];
+                *static_cast<lds_f4*>(__builtin_assume_aligned(row + K0 + 4 * j, 16)) = q;
+            }
+            // (the aligned pair among the remaining elements as one ds_write_b64 instead of the ds_write2_b32 the compiler
+            // forms: +2.3 % per launch, not kept)
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
                 if (k >= K0 && k < K0 + 4 * NG) continue;
                 const bool ok = SH < 0 ? (k < TPG - 1 || t0 + TPG < T) : (k > 0 || t0 > 0);   // index T resp. -1 does not exist
                 if (ok) row[k] = v[k];
             }
-            if (SH < 0 && t0 == 0) DST[i * TS] = 0.f;                      // time -1
-            if (SH > 0 && t0 + TPG == T) DST[i * TS + T - 1] = 0.f;        // time T
+            if (EDGE && SH < 0 && t0 == 0) DST[i * TS] = 0.f;                      // time -1
+            if (EDGE && SH > 0 && t0 + TPG == T) DST[i * TS + T - 1] = 0.f;        // time T
         }
     }
     // own elements -> HBM state vector (sample base already applied)
@@ -312,7 +325,7 @@ struct LdsCtx {
 // dc = diagonal coefficient of the own elements (H^T H or mask value, plus the rho/2 terms), see lds_diag.
 // Returns sum_k v_k * (A v)_k of the own elements.  Uses ctx.Q as scratch; contains a barrier for KIND 1.
 // Callers separate successive calls by barriers.
-template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND>
+template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND, bool EDGE = true>
 __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, const float (&v)[TPG], float (&av)[TPG], const float (&dc)[TPG],
                                            float c2) {
     float l[TPG];
@@ -324,7 +337,7 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, c
         for (int k = 0; k < TPG; ++k) q[k] = 0.f;
         if (c.active) c.op_ldr(c.P, v, q);
         if (SB) __syncthreads();           // single LDS vector (Q aliases P): every gather of p is done before q replaces it
-        c.template put<+1>(c.Q, q);
+        c.template put<+1, EDGE || SB>(c.Q, q);      // SB: p and q alternate in one vector, their zero slots included
         __syncthreads();
         if (c.active) c.op_ldrt(c.Q, q, l);
     } else if (KIND == 2) {
@@ -372,11 +385,11 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
         part += r[k] * r[k];
     }
     float rr = br.sumf(part);            // barrier: every read of P (= x0) is done
-    c.template put<SHP>(c.P, pv);
+    c.template put<SHP, SB>(c.P, pv);
     int iters = -1;
     for (int it = 0; it < max_cg; ++it) {
         __syncthreads();                 // p complete in LDS
-        part = lds_apply<TPG, BAND, KIND, SB, NU, ND>(c, pv, av, dc, c2);
+        part = lds_apply<TPG, BAND, KIND, SB, NU, ND, false>(c, pv, av, dc, c2);
         const float pAp = br.sumf(part);         // barrier: every gather from P/Q of this iteration is done
 #ifdef MGADMM_KO_FIXED           // knock-out timing builds run a fixed number of iterations on made-up coefficients
         const float alpha = 1e-3f + 0.f * pAp;
@@ -418,7 +431,7 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
 #endif
 #pragma unroll
         for (int k = 0; k < TPG; ++k) pv[k] = r[k] + beta * pv[k];
-        c.template put<SHP>(c.P, pv);
+        c.template put<SHP, SB>(c.P, pv);
     }
     return iters;
 }
