@@ -1295,7 +1295,7 @@ struct Engine : EngineBase {
         lds.off_en_u = off; off += 2 * nu;
         lds.off_en_d = off; off += 2 * nd;
         lds.off_en_t = off; off += 2 * nt;
-        off += 6;                      // three padding entries: the gather loop reads up to three entries ahead
+        off += 2 * (LDS_NLEAD + 3);    // padding entries: gather_lead reads LDS_NLEAD entries of the last row, the paired loop three ahead
         lds.csr_ints = off;
         // LDS row stride: T padded to an odd number of 16-byte slots (rows then start on every bank group);
         // fall back to the unpadded stride when the padded vectors do not fit

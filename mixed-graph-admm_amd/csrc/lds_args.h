@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// entries of a W_d^T row that k_admm_lds gathers up front (LdsCtx::gather_lead); the CSR image is padded accordingly
+constexpr int LDS_NLEAD = 4;
+
 struct LdsArgs {
     int T, N, TN, TS, t_in, G, B, Bp;   // TS: LDS row stride (floats) of a node's time row, >= T
     int nthreads;          // N * G active threads

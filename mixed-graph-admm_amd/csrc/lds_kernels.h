@@ -225,6 +225,62 @@ struct LdsCtx {
             for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
         }
     }
+    // Ragged rows (W_d^T: the in-degree of a kNN graph varies): the first NLEAD entries are read up front and gathered
+    // together like a fixed row -- entries past the end of the row belong to the next row (or to the padding of the
+    // table: NLEAD entries), they are read but enter with weight 0 --, the rest of a long row in the paired loop of
+    // `gather`.  The sum runs in entry order (a weight-0 term adds exactly 0).  One LDS latency chain for a typical row
+    // instead of one per pair of entries.
+    template <int NLEAD>
+    __device__ __forceinline__ void gather_lead(const float* SRC, const int2* EN, int e0, int e1, float (&acc)[TPG]) const {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
+#ifdef MGADMM_KO_NOGATHER
+        return;
+#endif
+        const float* base = SRC + t0;
+        const int len = e1 - e0;
+        int2 en[NLEAD];
+#pragma unroll
+        for (int u = 0; u < NLEAD; ++u) en[u] = EN[e0 + u];
+#pragma unroll
+        for (int u = 0; u < NLEAD; u += 2) {
+            float va[TPG], vb[TPG];
+            lds_load<TPG>(base + en[u].x, va);
+            if (u + 1 < NLEAD) lds_load<TPG>(base + en[u + 1].x, vb);
+            const float wa = u < len ? __int_as_float(en[u].y) : 0.f;
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
+            if (u + 1 < NLEAD) {
+                const float wb = u + 1 < len ? __int_as_float(en[u + 1].y) : 0.f;
+#pragma unroll
+                for (int k = 0; k < TPG; ++k) acc[k] += wb * vb[k];
+            }
+        }
+        if (len > NLEAD) {
+            int e = e0 + NLEAD;
+            int2 na = EN[e], nb = EN[e + 1];
+            for (; e + 1 < e1; e += 2) {
+                const int2 ea = na, eb = nb;
+                float va[TPG], vb[TPG];
+                lds_load<TPG>(base + ea.x, va);
+                lds_load<TPG>(base + eb.x, vb);
+                na = EN[e + 2];
+                nb = EN[e + 3];
+                const float wa = __int_as_float(ea.y), wb = __int_as_float(eb.y);
+#pragma unroll
+                for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
+#pragma unroll
+                for (int k = 0; k < TPG; ++k) acc[k] += wb * vb[k];
+            }
+            if (e < e1) {
+                float va[TPG];
+                lds_load<TPG>(base + na.x, va);
+                const float wa = __int_as_float(na.y);
+#pragma unroll
+                for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
+            }
+        }
+    }
     // band (line-graph) stencils on the node's own time row
     __device__ __forceinline__ void band_back(const float* SRC, float (&acc)[TPG]) const {
         const float* row = SRC + i * TS;
@@ -272,7 +328,7 @@ struct LdsCtx {
     // l = Ldr_T(src)    ADMM.py:179-223 (q1: identity kept on the t=0 block)
     __device__ __forceinline__ void op_ldrt(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
         float acc[TPG];
-        if constexpr (!BAND) gather(SRC, en_t, t0e, t1e, acc);     // SRC: image stored with put<+1>
+        if constexpr (!BAND) gather_lead<LDS_NLEAD>(SRC, en_t, t0e, t1e, acc);     // SRC: image stored with put<+1>
         else band_fwd(SRC, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((k > 0 || t0 > 0 || q1) ? self[k] : 0.f) - acc[k];
