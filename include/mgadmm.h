@@ -190,7 +190,9 @@ int mgadmm_initial_interpolation(mgadmm_solver* s, const void* y, const void* ma
 int mgadmm_cg(mgadmm_solver* s, int32_t which, const void* rhs, const void* x0, const void* mask, void* x,
               int32_t* iters, double* alpha, double* beta, int32_t B, void* stream);
 /* combined_loop(y, mask) (ADMM.py:511-648).  Prediction: mask NULL, y is (B, t_in, N).
- * Interpolation: y and mask are (B, T, N).  x_out is (B, T, N).  Synchronous. */
+ * Interpolation: y and mask are (B, T, N).  x_out is (B, T, N).  Synchronous.
+ * x_out and the state_out vectors may be written at any time during the call (the LDS-resident path iterates in place in
+ * them): they must not overlap y, mask or each other; state_in vectors may be the state_out vectors (resume in place). */
 int mgadmm_solve(mgadmm_solver* s, const void* y, const void* mask, int32_t mask_is_f32, int32_t B, void* x_out,
                  const mgadmm_state* state_out, mgadmm_history* hist, void* stream);
 

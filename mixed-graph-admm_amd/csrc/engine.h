@@ -1441,16 +1441,28 @@ struct Engine : EngineBase {
             MG_HIP(hipMemsetAsync(d_nonfinite, 0, sizeof(int), st));
             MG_HIP(hipMemsetAsync(d_ps, 0, sizeof(double) * MGADMM_NMETRIC * Bp, st));
             MG_HIP(hipMemsetAsync(d_cg_iters, 0, sizeof(int) * (size_t)max_it * 3 * Bp, st));
-            float *xa = vec[V_XA], *xb = vec[V_XB];
-            float *zu = vec[V_ZUA], *zd = vec[V_ZDA], *phi = vec[V_PHIA], *gam = vec[V_GAM], *gu = vec[V_GU], *gd = vec[V_GD];
+            // The caller's output buffers ARE the working state of this path (same (B, T*N) layout): no copy-out at the end
+            // (round 2 until here: seven 120 MB device copies per solve at cfg2 = 0.7 ms of a 59 ms solve).  x alternates
+            // between two buffers; they are assigned so that the iterate of the LAST iteration lands in x_out (an early
+            // stop on the other parity costs one copy).  Outputs must not alias y / mask (mgadmm.h).
+            auto pick = [&](void* out, float* own) { return out ? static_cast<float*>(out) : own; };
+            float* const xo_ = static_cast<float*>(x_out);
+            float *xa = (max_it & 1) ? vec[V_XA] : xo_, *xb = (max_it & 1) ? xo_ : vec[V_XA];
+            float *zu = pick(state_out ? state_out->zu : nullptr, vec[V_ZUA]), *zd = pick(state_out ? state_out->zd : nullptr, vec[V_ZDA]);
+            float *phi = pick(state_out && has_phi ? state_out->phi : nullptr, vec[V_PHIA]), *gam = pick(state_out && has_phi ? state_out->gamma : nullptr, vec[V_GAM]);
+            float *gu = pick(state_out ? state_out->gamma_u : nullptr, vec[V_GU]), *gd = pick(state_out ? state_out->gamma_d : nullptr, vec[V_GD]);
             if (state_in) {                   // warm start: the state tensors are already in this path's (B, T*N) layout
                 const size_t nb = (size_t)B * TN * sizeof(float);
-                auto cp = [&](float* dst, const void* src) { return hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, st); };
+                auto cp = [&](float* dst, const void* src) {
+                    return (src == nullptr || dst == src) ? hipSuccess : hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, st);
+                };
                 MG_HIP(cp(xa, x0));
                 MG_HIP(cp(zu, state_in->zu));
                 MG_HIP(cp(gu, state_in->gamma_u));
-                if (has_zd) { MG_HIP(cp(zd, state_in->zd)); MG_HIP(cp(gd, state_in->gamma_d)); }
-                if (has_phi) { MG_HIP(cp(phi, state_in->phi)); MG_HIP(cp(gam, state_in->gamma)); }
+                MG_HIP(cp(zd, state_in->zd));            // the vectors an ablation does not iterate on are carried through
+                MG_HIP(cp(gd, state_in->gamma_d));
+                MG_HIP(cp(phi, state_in->phi));
+                MG_HIP(cp(gam, state_in->gamma));
             } else {
                 float tm = 0, t2m = 0;
                 for (int t = 0; t < p.t_in; ++t) { tm += (float)t; t2m += (float)t * (float)t; }
@@ -1531,16 +1543,8 @@ struct Engine : EngineBase {
                     if (pri < p.admm_tol && dual < p.admm_tol) break;
                 }
             }
-            const size_t bytes = (size_t)B * TN * sizeof(float);
-            MG_HIP(hipMemcpyAsync(x_out, xc, bytes, hipMemcpyDeviceToDevice, st));
-            if (state_out) {
-                if (state_out->zu) MG_HIP(hipMemcpyAsync(state_out->zu, zu, bytes, hipMemcpyDeviceToDevice, st));
-                if (state_out->zd) MG_HIP(hipMemcpyAsync(state_out->zd, zd, bytes, hipMemcpyDeviceToDevice, st));
-                if (state_out->phi && has_phi) MG_HIP(hipMemcpyAsync(state_out->phi, phi, bytes, hipMemcpyDeviceToDevice, st));
-                if (state_out->gamma && has_phi) MG_HIP(hipMemcpyAsync(state_out->gamma, gam, bytes, hipMemcpyDeviceToDevice, st));
-                if (state_out->gamma_u) MG_HIP(hipMemcpyAsync(state_out->gamma_u, gu, bytes, hipMemcpyDeviceToDevice, st));
-                if (state_out->gamma_d) MG_HIP(hipMemcpyAsync(state_out->gamma_d, gd, bytes, hipMemcpyDeviceToDevice, st));
-            }
+            if (xc != xo_)        // early stop on the other parity
+                MG_HIP(hipMemcpyAsync(x_out, xc, (size_t)B * TN * sizeof(float), hipMemcpyDeviceToDevice, st));
             return finish_history(hist, n_done, B, Bp, rc_final);
         }
     }
