@@ -929,12 +929,56 @@ __global__ __launch_bounds__(256) void k_dxps_sm(int TN, int B, const float* __r
     part[(size_t)blockIdx.y * TN + e] = s;
 }
 
+// the same with four consecutive elements per thread (16-byte loads; T*N a multiple of 4 and 16-byte aligned vectors):
+// 61 -> 4x fewer load instructions for the 2 * B * T*N * 4 bytes this pass streams
+__global__ __launch_bounds__(256) void k_dxps_sm4(int TN, int B, const float* __restrict__ x, const float* __restrict__ xo,
+                                                  double* __restrict__ part) {
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= TN) return;
+    const int b0 = blockIdx.y * 64, b1 = min(B, b0 + 64);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
+        lds_f4 a[4], o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const lds_f4*>(x + (size_t)(b + u) * TN + e);
+            o[u] = *reinterpret_cast<const lds_f4*>(xo + (size_t)(b + u) * TN + e);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            s0 += (double)a[u].x - (double)o[u].x;
+            s1 += (double)a[u].y - (double)o[u].y;
+            s2 += (double)a[u].z - (double)o[u].z;
+            s3 += (double)a[u].w - (double)o[u].w;
+        }
+    }
+    for (; b < b1; ++b) {
+        const lds_f4 a = *reinterpret_cast<const lds_f4*>(x + (size_t)b * TN + e);
+        const lds_f4 o = *reinterpret_cast<const lds_f4*>(xo + (size_t)b * TN + e);
+        s0 += (double)a.x - (double)o.x;
+        s1 += (double)a.y - (double)o.y;
+        s2 += (double)a.z - (double)o.z;
+        s3 += (double)a.w - (double)o.w;
+    }
+    double* dst = part + (size_t)blockIdx.y * TN + e;
+    dst[0] = s0; dst[1] = s1; dst[2] = s2; dst[3] = s3;
+}
+
 __global__ __launch_bounds__(256) void k_dxps_sm_mean(int TN, int B, int nslices, const double* __restrict__ part,
                                                       double* __restrict__ m2) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= TN) return;
     double s = 0.0;
-    for (int k = 0; k < nslices; ++k) s += part[(size_t)k * TN + e];
+    int k = 0;
+    for (; k + 8 <= nslices; k += 8) {        // eight slices per trip in flight (one per trip: 64 dependent L2 round trips, 17 us); same order of additions
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u) * TN + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nslices; ++k) s += part[(size_t)k * TN + e];
     s /= (double)B;
     m2[e] = s * s;
 }

@@ -3,6 +3,7 @@
 #include <utility>
 #include <vector>
 
+#include <cstdint>
 #include "lds_kernels.h"
 
 namespace {
@@ -71,7 +72,10 @@ int mg_lds_init(bool masked, int T, int t_in, int N, int B, float tm, float den,
 
 int mg_lds_dxps(int T, int N, int B, const float* x, const float* xo, double* scratch, double* out, hipStream_t st) {
     const int TN = T * N, nsl = (B + 63) / 64;
-    hipLaunchKernelGGL(k_dxps_sm, dim3((TN + 255) / 256, nsl), dim3(256), 0, st, TN, B, x, xo, scratch + TN);
+    if (TN % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)xo % 16) == 0)
+        hipLaunchKernelGGL(k_dxps_sm4, dim3((TN / 4 + 255) / 256, nsl), dim3(256), 0, st, TN, B, x, xo, scratch + TN);
+    else
+        hipLaunchKernelGGL(k_dxps_sm, dim3((TN + 255) / 256, nsl), dim3(256), 0, st, TN, B, x, xo, scratch + TN);
     hipLaunchKernelGGL(k_dxps_sm_mean, dim3((TN + 255) / 256), dim3(256), 0, st, TN, B, nsl, (const double*)(scratch + TN), scratch);
     hipLaunchKernelGGL(k_dxps_sm_final, dim3(T), dim3(256), 0, st, T, N, (const double*)scratch, out);
     MG_HIP(hipGetLastError());
