@@ -72,6 +72,7 @@ struct Engine : EngineBase {
     } cldr_dev;
     int use_fused = 1;            // MGADMM_FUSED=0 keeps the two-pass cLdr (tests compare the two)
     int use_fold = 1;             // MGADMM_FOLD=0: p = r + beta p and x += alpha p stay in their own kernel (EpiPUpdate)
+    int use_fold_lu = 1;          // MGADMM_FOLD_LU=0: the same for the Lu kernel of the zu solve only
     int sweep_rev = 1;            // MGADMM_SWEEP_REV=0: r -= alpha Ap sweeps the time slices upwards like every other kernel
     int cldr_tile_major = 1;      // MGADMM_CLDR_ORDER=0: chunks of a tile adjacent in dispatch order
     int cur_P = 0;                // partial rows written by the last row-kernel launch (k_rows or k_tile)
@@ -404,6 +405,7 @@ struct Engine : EngineBase {
         if (const char* e = getenv("MGADMM_TILE")) use_tile = atoi(e);
         if (const char* e = getenv("MGADMM_FUSED")) use_fused = atoi(e);
         if (const char* e = getenv("MGADMM_FOLD")) use_fold = atoi(e);
+        if (const char* e = getenv("MGADMM_FOLD_LU")) use_fold_lu = atoi(e);
         if (const char* e = getenv("MGADMM_SWEEP_REV")) sweep_rev = atoi(e);
         if (const char* e = getenv("MGADMM_CLDR_ORDER")) cldr_tile_major = atoi(e);
         Geom q = make_geom(Bmax);
@@ -589,7 +591,37 @@ struct Engine : EngineBase {
         auto fn = k_tile<S, VEC, Epi, TGW, MR>;
         MG_TRY(allow_dynamic_lds((const void*)fn, 80 * 1024));
         hipLaunchKernelGGL(fn, dim3(tg.grid), dim3(256), tg.lds_bytes, st, tg, op, tmv.tl_col, tmv.tl_w, tmv.halo, tmv.h_rowptr,
-                           tmv.h_col, tmv.h_val, in, epi, partials, live);
+                           tmv.h_col, tmv.h_val, in, epi, partials, live, TileSrcPlain<S, VEC>());
+        return MGADMM_OK;
+    }
+
+    // ---- Lu with the CG vector update folded into its loads (k_tile with TileSrcFold): zu solve.  Built for the
+    // production shape only (k = 4 table: 4 slots per row; 8-row tiles; the solver's widest vector): other shapes keep
+    // the separate EpiPUpdate launch.
+    static constexpr int LU_FOLD_VEC = sizeof(S) == 4 ? 4 : 2;
+    bool lu_fold_fits(const Geom& q) {
+        TileGeom tg;
+        if (!use_fold || !use_fold_lu || !use_tile || g->reorder < 2 || q.VEC != LU_FOLD_VEC || g->Wu.max_row > 4) return false;
+        return make_tile_geom(q, tg) && tg.R != 20;
+    }
+    template <template <typename, int> class E, class... A>
+    int rows_lu_fold(const Geom& q, const S* r, const S* p_old, S* p_new, S* x, const int* live, int tag, int passes, A... a) {
+        constexpr int VEC = LU_FOLD_VEC;
+        typedef E<S, VEC> Epi;
+        typedef TileSrcFold<S, VEC> Src;
+        const OpDesc op = g->op_lu();
+        const bool timed = prof_open(tag, pass_bytes(q, passes) + csr_bytes(op));
+        TileGeom tg;
+        if (!make_tile_geom(q, tg)) { mg_set_error("rows_lu_fold: no tile geometry"); return MGADMM_ERR_INVALID; }
+        TileMeta tmv;
+        MG_TRY(tile_meta(0, tg.R, 4, tmv));
+        auto fn = k_tile<S, VEC, Epi, 4, 2, Src>;
+        MG_TRY(allow_dynamic_lds((const void*)fn, 80 * 1024));
+        hipLaunchKernelGGL(fn, dim3(tg.grid), dim3(256), tg.lds_bytes, st, tg, op, tmv.tl_col, tmv.tl_w, tmv.halo, tmv.h_rowptr,
+                           tmv.h_col, tmv.h_val, r, Epi{a...}, partials, live, Src{p_old, p_new, x, d_alpha, d_beta});
+        cur_P = tg.P;
+        if (timed) prof_close();
+        MG_HIP(hipGetLastError());
         return MGADMM_OK;
     }
 
@@ -795,13 +827,19 @@ struct Engine : EngineBase {
         // kind 1 on the fused kernel: the vector update of iteration k (p = r + beta p, x += alpha p) is folded into the
         // SpMM launch of iteration k+1 (k_cldr with CldrSrcFold); p alternates between two buffers because other tiles
         // still gather the old direction for their halos.  The x update of the last iteration is applied after the loop.
-        const bool fold = d.kind == 1 && use_fold && cldr_fits(q);
+        const bool fold1 = d.kind == 1 && use_fold && cldr_fits(q);
+        const bool fold2 = d.kind == 2 && lu_fold_fits(q);      // zu solve: the same fold in the LDS-tiled Lu kernel
+        const bool fold = fold1 || fold2;
         S* pbuf[2] = {pp, vec[V_Q]};          // V_Q is free: the fused kernel keeps q = Ldr p on chip
         int k = 0;
         for (; k < K; ++k) {
             const int* live = k == 0 ? nullptr : d_nact + (k - 1);
             prof_cur_ref = (k == 0 || nact_locked) ? -1 : base + k - 1;
-            if (fold) {
+            if (fold2) {
+                // 1 SpMM application (8 B/element) + the absorbed vector update (20 B/element) per launch
+                MG_TRY(rows_lu_fold<EpiLhs>(q, r, pbuf[k & 1], pbuf[(k + 1) & 1], xout, live, 0, 7, (const S*)nullptr, (const S*)nullptr, Ap,
+                                            d.hth, p.t_in, (S)d.c1, (S)d.c2));
+            } else if (fold1) {
                 // 2 SpMM applications (16 B/element) + the absorbed vector update (20 B/element) per launch
                 MG_TRY(rows_cldr_fold<EpiLhs>(q, r, pbuf[k & 1], pbuf[(k + 1) & 1], xout, live, 0, 9, (const S*)nullptr, (const S*)nullptr, Ap,
                                               d.hth, p.t_in, (S)d.c1, (S)d.c2));

@@ -348,12 +348,33 @@ struct TileMeta {
 // LDS reads of one row overlap the FMAs of the previous one, no per-row branches) and the register arrays
 // hold exactly MR rows.  Rows past the end of a short last tile are clamped to the tile's last row for their
 // loads and gathers and skip the epilogue.
-template <typename S, int VEC, class Epi, int TILE_GW, int MR>
+// Where the vector the operator is applied to comes from (as for k_cldr):
+//   TileSrcPlain : x = in.
+//   TileSrcFold  : Lu only (shift 0).  The CG direction is formed ON LOAD, x = p_new = r + beta p_old (ADMM.py:366; `in` is r),
+//                  for the own rows and for the halo rows; the owner of a row also stores p_new and applies the deferred
+//                  x += alpha p_old (ADMM.py:352): the vector-update kernel of the previous CG iteration of the zu solve
+//                  (EpiPUpdate, 20 B/element) disappears into this launch.  p_new goes to a second buffer: other
+//                  workgroups still read p_old for their halos.
+template <typename S, int VEC>
+struct TileSrcPlain {
+    static constexpr bool FOLD = false;
+};
+template <typename S, int VEC>
+struct TileSrcFold {
+    static constexpr bool FOLD = true;
+    const S* p_old;
+    S* p_new;
+    S* x;
+    const S* alpha;
+    const S* beta;
+};
+
+template <typename S, int VEC, class Epi, int TILE_GW, int MR, class Src = TileSrcPlain<S, VEC>>
 __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* __restrict__ tl_col,
                                               const float* __restrict__ tl_w, const int* __restrict__ halo,
                                               const int* __restrict__ h_rowptr, const int* __restrict__ h_col,
                                               const float* __restrict__ h_val, const S* __restrict__ in, Epi epi_in,
-                                              S* __restrict__ partials, const int* __restrict__ live) {
+                                              S* __restrict__ partials, const int* __restrict__ live, Src src = Src()) {
     static_assert(MR * TILE_GW <= 64 && MR <= TILE_MAXR, "per-row metadata must fit the 64 lanes of a wave");
     extern __shared__ __align__(16) unsigned char tile_raw[];
     if (live != nullptr && *live == 0) return;
@@ -411,12 +432,56 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
         const S* trow = tile + lane * VEC;
         S* hdst = tile + (size_t)R * W + lane * VEC;
         auto step_t = [&](int sidx) { return shift > 0 ? g.T - 1 - sidx : sidx; };
+        S fa[VEC], fb[VEC];             // FOLD: alpha, beta of this lane's columns
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) fa[v] = fb[v] = S(0);
+        if constexpr (Src::FOLD) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                fa[v] = src.alpha[col0 + v];
+                fb[v] = src.beta[col0 + v];
+            }
+        }
+        // FOLD: p_new = r + beta p_old of any row (halo rows, overflow neighbours): nothing stored
+        auto folded = [&](size_t off) {
+            Vec<S, VEC> rv = ldv<S, VEC>(in + off);
+            if constexpr (Src::FOLD) {
+                const Vec<S, VEC> po = ldv<S, VEC>(src.p_old + off);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) rv.v[v] = fma(fb[v], po.v[v], rv.v[v]);
+            }
+            return rv;
+        };
+        constexpr int MRF = Src::FOLD ? MR : 1;
+        // FOLD: an own row becomes p_new; its owner stores p_new and x += alpha p_old (same roundings as EpiPUpdate)
+        auto own_combine = [&](int tt, int j, const Vec<S, VEC>& rv, const Vec<S, VEC>& po, const Vec<S, VEC>& xo) {
+            Vec<S, VEC> pv = rv;
+            if constexpr (Src::FOLD) {
+                Vec<S, VEC> xv;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    xv.v[v] = fma(fa[v], po.v[v], xo.v[v]);
+                    pv.v[v] = fma(fb[v], po.v[v], rv.v[v]);
+                }
+                if (rowok[j]) {
+                    const size_t off = ((size_t)tt * g.N + rowi[j]) * g.Bp + col0;
+                    stv<S, VEC>(src.x + off, xv);
+                    stv<S, VEC>(src.p_new + off, pv);
+                }
+            }
+            return pv;
+        };
         // own rows of the first step; afterwards the own rows of step s+1 are requested while step s computes
         Vec<S, VEC> own[MR];
         {
-            const S* obase = in + (size_t)step_t(0) * g.N * g.Bp + col0;
+            const size_t ob = (size_t)step_t(0) * g.N * g.Bp + col0;
 #pragma unroll
-            for (int j = 0; j < MR; ++j) own[j] = ldv<S, VEC>(obase + (size_t)rowi[j] * g.Bp);
+            for (int j = 0; j < MR; ++j) {
+                const size_t off = ob + (size_t)rowi[j] * g.Bp;
+                const Vec<S, VEC> rv = ldv<S, VEC>(in + off);
+                if constexpr (Src::FOLD) own[j] = own_combine(step_t(0), j, rv, ldv<S, VEC>(src.p_old + off), ldv<S, VEC>(src.x + off));
+                else own[j] = rv;
+            }
         }
         for (int step = 0; step < g.T; ++step) {
             const int t = step_t(step);
@@ -425,7 +490,6 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
             S selfc = S(1);
             if (op.self_mode == SELF_LDR) selfc = (t >= 1) ? S(1) : S(0);
             else if (op.self_mode == SELF_LDRT) selfc = (t > 0 || op.q1) ? S(1) : S(0);
-            const S* gbase = in + (size_t)(tvalid ? ts : t) * g.N * g.Bp + col0;
             // 1. requests of this step, in the order they are needed: halo rows of the gathered slice, the
             //    epilogue's operand rows, and the own rows of the NEXT step
             Vec<S, VEC> hv[TILE_HPW];
@@ -433,7 +497,7 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
 #pragma unroll
                 for (int k = 0; k < TILE_HPW; ++k) {
                     const int hr = __builtin_amdgcn_readlane(hrow, k);
-                    if (hr >= 0) hv[k] = ldv<S, VEC>(gbase + (size_t)hr * g.Bp);
+                    if (hr >= 0) hv[k] = folded((size_t)(tvalid ? ts : t) * g.N * g.Bp + col0 + (size_t)hr * g.Bp);
                 }
             }
             Vec<S, VEC> pre[MR];
@@ -441,11 +505,18 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
 #pragma unroll
                 for (int j = 0; j < MR; ++j) pre[j] = epi.pre(((size_t)t * g.N + rowi[j]) * g.Bp + col0);
             }
-            Vec<S, VEC> ownn[MR];
+            Vec<S, VEC> ownn[MR], pon[MRF], xon[MRF];      // FOLD: r, p_old, x of the next step's own rows
             {
-                const S* nbase = in + (size_t)step_t(min(step + 1, g.T - 1)) * g.N * g.Bp + col0;
+                const size_t nb = (size_t)step_t(min(step + 1, g.T - 1)) * g.N * g.Bp + col0;
 #pragma unroll
-                for (int j = 0; j < MR; ++j) ownn[j] = ldv<S, VEC>(nbase + (size_t)rowi[j] * g.Bp);
+                for (int j = 0; j < MR; ++j) {
+                    const size_t off = nb + (size_t)rowi[j] * g.Bp;
+                    ownn[j] = ldv<S, VEC>(in + off);
+                    if constexpr (Src::FOLD) {
+                        pon[j] = ldv<S, VEC>(src.p_old + off);
+                        xon[j] = ldv<S, VEC>(src.x + off);
+                    }
+                }
             }
             if (tvalid) {
 #pragma unroll
@@ -489,7 +560,7 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
                     if (hcount > 0) {
                         const int hstart = __builtin_amdgcn_readlane(hs, j);
                         for (int e = hstart; e < hstart + hcount; ++e) {
-                            const Vec<S, VEC> x = ldv<S, VEC>(gbase + (size_t)h_col[e] * g.Bp);
+                            const Vec<S, VEC> x = folded((size_t)(tvalid ? ts : t) * g.N * g.Bp + col0 + (size_t)h_col[e] * g.Bp);
                             const S w = (S)h_val[e];
 #pragma unroll
                             for (int v = 0; v < VEC; ++v) sum.v[v] += w * x.v[v];
@@ -513,8 +584,15 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
 #pragma unroll
                 for (int j = 0; j < MR; ++j) stl<S, VEC>(tile + (size_t)(wave + 4 * j) * W + lane * VEC, own[j]);
             }
+            if constexpr (Src::FOLD) {
+                if (step + 1 < g.T) {
 #pragma unroll
-            for (int j = 0; j < MR; ++j) own[j] = ownn[j];
+                    for (int j = 0; j < MR; ++j) own[j] = own_combine(step_t(step + 1), j, ownn[j], pon[j], xon[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < MR; ++j) own[j] = ownn[j];
+            }
         }
     }
 

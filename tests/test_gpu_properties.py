@@ -97,6 +97,23 @@ def test_cfg3_fused_cldr_kernel_equals_two_pass_form(cfg3, monkeypatch):
     two.close()
 
 
+def test_cfg3_zu_solve_with_the_vector_update_folded_into_the_lu_kernel_is_bitwise_the_separate_form(cfg3, monkeypatch):
+    """The zu solve runs k_tile with TileSrcFold (p = r + beta p formed on load for tile and halo rows, x += alpha p
+    applied by the owner); MGADMM_FOLD_LU=0 keeps the separate EpiPUpdate launch.  Same fma's in the same order: the
+    solutions and the iteration counts are identical bit for bit."""
+    blk, n, B = cfg3
+    g = torch.Generator(device="cuda").manual_seed(9)
+    rhs = torch.randn(256, 24, n, 1, device="cuda", generator=g)
+    x0 = torch.randn(256, 24, n, 1, device="cuda", generator=g)
+    monkeypatch.setenv("MGADMM_FOLD_LU", "0")
+    sep, _, _ = _solver("cfg3", bug_compat=False)
+    xa, ia, aa, ba = blk.CG_solver(blk.LHS_zu, rhs, x0)
+    xb, ib, ab, bb = sep.CG_solver(sep.LHS_zu, rhs, x0)
+    assert torch.equal(ia, ib) and int(ia.min()) > 1
+    assert torch.equal(xa, xb)
+    sep.close()
+
+
 def test_cfg3_cg_solves_the_system_per_sample(cfg3):
     """After CG_solver, A x = b holds to the recursive-residual tolerance and every sample reports its own count."""
     blk, n, B = cfg3
