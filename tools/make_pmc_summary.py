@@ -17,7 +17,7 @@ def short(n):
         return f"k_cldr<{m.group(3)},{m.group(4)}>"
     m = re.search(r'(k_rows|k_tile)<(\w+), (\d+), (\w+)(?:<[^>]*>)?, (\d+)', n)
     if m:
-        return f"{m.group(1)}<{m.group(4)},GW{m.group(5)}>"
+        return f"{m.group(1)}<{m.group(4)},GW{m.group(5)}{',Fold' if 'TileSrcFold' in n else ''}>"
     m = re.search(r'k_admm_lds<(\d+), (\w+)', n)
     if m:
         return f"k_admm_lds<{m.group(1)},{m.group(2)}>"
