@@ -195,8 +195,10 @@ struct LdsCtx {
     // The same for a matrix whose rows all hold exactly NFIX entries (W_u: k, W_d: k + 1 of a kNN table without pads):
     // straight-line code, every entry of the row is read up front, no per-lane trip count -- the divergent loop above
     // costs an exec-mask region and a register copy per accumulator and trip.
+    // PRE != nullptr: the row's entries were read once before the CG loop and live in registers (they do not change
+    // during a solve): no entry reads, and the neighbour reads no longer wait for them, inside the loop
     template <int NFIX>
-    __device__ __forceinline__ void gather_fixed(const float* SRC, const int2* EN, int e0, float (&acc)[TPG]) const {
+    __device__ __forceinline__ void gather_fixed(const float* SRC, const int2* EN, int e0, float (&acc)[TPG], const int2* PRE = nullptr) const {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
 #ifdef MGADMM_KO_NOGATHER
@@ -205,7 +207,7 @@ struct LdsCtx {
         const float* base = SRC + t0;
         int2 en[NFIX];
 #pragma unroll
-        for (int u = 0; u < NFIX; ++u) en[u] = EN[e0 + u];
+        for (int u = 0; u < NFIX; ++u) en[u] = PRE ? PRE[u] : EN[e0 + u];
 #pragma unroll
         for (int u = 0; u + 1 < NFIX; u += 2) {
             float va[TPG], vb[TPG];
@@ -309,18 +311,18 @@ struct LdsCtx {
         }
     }
     // l = Lu(src): neighbours from SRC (LDS), the thread's own elements of src from registers (self)     ADMM.py:138-148
-    __device__ __forceinline__ void op_lu(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
+    __device__ __forceinline__ void op_lu(const float* SRC, const float (&self)[TPG], float (&l)[TPG], const int2* PRE = nullptr) const {
         float acc[TPG];
-        if constexpr (NU > 0) gather_fixed<NU>(SRC, en_u, u0, acc);
+        if constexpr (NU > 0) gather_fixed<NU>(SRC, en_u, u0, acc, PRE);
         else gather(SRC, en_u, u0, u1, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = self[k] - acc[k];
     }
     // l = Ldr(src)      ADMM.py:150-177
-    __device__ __forceinline__ void op_ldr(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
+    __device__ __forceinline__ void op_ldr(const float* SRC, const float (&self)[TPG], float (&l)[TPG], const int2* PRE = nullptr) const {
         float acc[TPG];
         if constexpr (BAND) band_back(SRC, acc);
-        else if constexpr (ND > 0) gather_fixed<ND>(SRC, en_d, d0, acc);       // SRC: image stored with put<-1>
+        else if constexpr (ND > 0) gather_fixed<ND>(SRC, en_d, d0, acc, PRE);       // SRC: image stored with put<-1>
         else gather(SRC, en_d, d0, d1, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((k >= 1 || t0 >= 1) ? self[k] : 0.f) - acc[k];
@@ -383,7 +385,7 @@ struct LdsCtx {
 // Callers separate successive calls by barriers.
 template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND, bool EDGE = true>
 __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, const float (&v)[TPG], float (&av)[TPG], const float (&dc)[TPG],
-                                           float c2) {
+                                           float c2, const int2* PRE = nullptr) {
     float l[TPG];
 #pragma unroll
     for (int k = 0; k < TPG; ++k) l[k] = 0.f;
@@ -391,13 +393,13 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, c
         float q[TPG];
 #pragma unroll
         for (int k = 0; k < TPG; ++k) q[k] = 0.f;
-        if (c.active) c.op_ldr(c.P, v, q);
+        if (c.active) c.op_ldr(c.P, v, q, PRE);
         if (SB) __syncthreads();           // single LDS vector (Q aliases P): every gather of p is done before q replaces it
         c.template put<+1, EDGE || SB>(c.Q, q);      // SB: p and q alternate in one vector, their zero slots included
         __syncthreads();
         if (c.active) c.op_ldrt(c.Q, q, l);
     } else if (KIND == 2) {
-        if (c.active) c.op_lu(c.P, v, l);
+        if (c.active) c.op_lu(c.P, v, l, PRE);
     }
     float part = 0.f;
 #pragma unroll
@@ -442,10 +444,19 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
     }
     float rr = br.sumf(part);            // barrier: every read of P (= x0) is done
     c.template put<SHP, SB>(c.P, pv);
+    // entries of this thread's fixed-length row (W_d for the cLdr solves, W_u for the zu solve), once per solve
+    constexpr int NPRE = (KIND == 1 && !BAND && ND > 0) ? ND : ((KIND == 2 && NU > 0) ? NU : 0);
+    int2 pre[NPRE > 0 ? NPRE : 1];
+    if constexpr (NPRE > 0) {
+        const int2* EN = KIND == 1 ? c.en_d : c.en_u;
+        const int e0 = KIND == 1 ? c.d0 : c.u0;
+#pragma unroll
+        for (int u = 0; u < NPRE; ++u) pre[u] = EN[e0 + u];
+    }
     int iters = -1;
     for (int it = 0; it < max_cg; ++it) {
         __syncthreads();                 // p complete in LDS
-        part = lds_apply<TPG, BAND, KIND, SB, NU, ND, false>(c, pv, av, dc, c2);
+        part = lds_apply<TPG, BAND, KIND, SB, NU, ND, false>(c, pv, av, dc, c2, NPRE > 0 ? pre : nullptr);
         const float pAp = br.sumf(part);         // barrier: every gather from P/Q of this iteration is done
 #ifdef MGADMM_KO_FIXED           // knock-out timing builds run a fixed number of iterations on made-up coefficients
         const float alpha = 1e-3f + 0.f * pAp;
