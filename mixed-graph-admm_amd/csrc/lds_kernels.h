@@ -233,7 +233,7 @@ struct LdsCtx {
     // `gather`.  The sum runs in entry order (a weight-0 term adds exactly 0).  One LDS latency chain for a typical row
     // instead of one per pair of entries.
     template <int NLEAD>
-    __device__ __forceinline__ void gather_lead(const float* SRC, const int2* EN, int e0, int e1, float (&acc)[TPG]) const {
+    __device__ __forceinline__ void gather_lead(const float* SRC, const int2* EN, int e0, int e1, float (&acc)[TPG], const int2* PRE = nullptr) const {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
 #ifdef MGADMM_KO_NOGATHER
@@ -243,7 +243,7 @@ struct LdsCtx {
         const int len = e1 - e0;
         int2 en[NLEAD];
 #pragma unroll
-        for (int u = 0; u < NLEAD; ++u) en[u] = EN[e0 + u];
+        for (int u = 0; u < NLEAD; ++u) en[u] = PRE ? PRE[u] : EN[e0 + u];
 #pragma unroll
         for (int u = 0; u < NLEAD; u += 2) {
             float va[TPG], vb[TPG];
@@ -328,9 +328,9 @@ struct LdsCtx {
         for (int k = 0; k < TPG; ++k) l[k] = ((k >= 1 || t0 >= 1) ? self[k] : 0.f) - acc[k];
     }
     // l = Ldr_T(src)    ADMM.py:179-223 (q1: identity kept on the t=0 block)
-    __device__ __forceinline__ void op_ldrt(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
+    __device__ __forceinline__ void op_ldrt(const float* SRC, const float (&self)[TPG], float (&l)[TPG], const int2* PRE = nullptr) const {
         float acc[TPG];
-        if constexpr (!BAND) gather_lead<LDS_NLEAD>(SRC, en_t, t0e, t1e, acc);     // SRC: image stored with put<+1>
+        if constexpr (!BAND) gather_lead<LDS_NLEAD>(SRC, en_t, t0e, t1e, acc, PRE);     // SRC: image stored with put<+1>
         else band_fwd(SRC, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((k > 0 || t0 > 0 || q1) ? self[k] : 0.f) - acc[k];
@@ -385,7 +385,7 @@ struct LdsCtx {
 // Callers separate successive calls by barriers.
 template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND, bool EDGE = true>
 __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, const float (&v)[TPG], float (&av)[TPG], const float (&dc)[TPG],
-                                           float c2, const int2* PRE = nullptr) {
+                                           float c2, const int2* PRE = nullptr, const int2* PRET = nullptr) {
     float l[TPG];
 #pragma unroll
     for (int k = 0; k < TPG; ++k) l[k] = 0.f;
@@ -397,7 +397,7 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, c
         if (SB) __syncthreads();           // single LDS vector (Q aliases P): every gather of p is done before q replaces it
         c.template put<+1, EDGE || SB>(c.Q, q);      // SB: p and q alternate in one vector, their zero slots included
         __syncthreads();
-        if (c.active) c.op_ldrt(c.Q, q, l);
+        if (c.active) c.op_ldrt(c.Q, q, l, PRET);
     } else if (KIND == 2) {
         if (c.active) c.op_lu(c.P, v, l, PRE);
     }
@@ -453,10 +453,16 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
 #pragma unroll
         for (int u = 0; u < NPRE; ++u) pre[u] = EN[e0 + u];
     }
+    constexpr int NPRET = (KIND == 1 && !BAND) ? LDS_NLEAD : 0;      // ... and the leading entries of its W_d^T row
+    int2 pret[NPRET > 0 ? NPRET : 1];
+    if constexpr (NPRET > 0) {
+#pragma unroll
+        for (int u = 0; u < NPRET; ++u) pret[u] = c.en_t[c.t0e + u];
+    }
     int iters = -1;
     for (int it = 0; it < max_cg; ++it) {
         __syncthreads();                 // p complete in LDS
-        part = lds_apply<TPG, BAND, KIND, SB, NU, ND, false>(c, pv, av, dc, c2, NPRE > 0 ? pre : nullptr);
+        part = lds_apply<TPG, BAND, KIND, SB, NU, ND, false>(c, pv, av, dc, c2, NPRE > 0 ? pre : nullptr, NPRET > 0 ? pret : nullptr);
         const float pAp = br.sumf(part);         // barrier: every gather from P/Q of this iteration is done
 #ifdef MGADMM_KO_FIXED           // knock-out timing builds run a fixed number of iterations on made-up coefficients
         const float alpha = 1e-3f + 0.f * pAp;
