@@ -467,7 +467,11 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
 #ifdef MGADMM_KO_FIXED           // knock-out timing builds run a fixed number of iterations on made-up coefficients
         const float alpha = 1e-3f + 0.f * pAp;
 #else
-        const float alpha = rr / pAp;
+        // alpha, beta through v_rcp_f32 (1 ulp) instead of the correctly rounded division (a chain of ~10 dependent
+        // instructions every thread waits for, twice per iteration: -2.9 % per launch).  The coefficients differ from
+        // the IEEE quotient by at most 1.5 ulp -- below the rounding noise of the dot products they are formed from;
+        // the streaming path keeps the IEEE division (its coefficients come from a separate tiny kernel).
+        const float alpha = rr * __builtin_amdgcn_rcpf(pAp);
 #endif
         part = 0.f;
 #pragma unroll
@@ -480,7 +484,7 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
 #ifdef MGADMM_KO_FIXED
         const float beta = 0.5f + 0.f * rrn;
 #else
-        const float beta = rrn / rr;
+        const float beta = rrn * __builtin_amdgcn_rcpf(rr);
 #endif
         rr = rrn;
         if (ah != nullptr && threadIdx.x == 0) {
