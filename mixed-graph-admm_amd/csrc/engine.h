@@ -87,6 +87,13 @@ struct Engine : EngineBase {
     } lds;
     int* d_lds_csr = nullptr;
     double* d_m2 = nullptr;
+    // ADMM outer loop of the LDS path without host round trips (solve_lds): device stop word, second metric buffer, helper
+    // stream for the whole-batch metric kernels and the events that order the two streams
+    int lds_async = 1;            // MGADMM_LDS_ASYNC=0: one stream, the host tests the stop criterion after every iteration
+    int* d_stop = nullptr;
+    double* d_ps2 = nullptr;
+    hipStream_t st_side = nullptr;
+    hipEvent_t ev_main[3] = {nullptr}, ev_side[3] = {nullptr};
     // profiling
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -108,7 +115,10 @@ struct Engine : EngineBase {
         auto fr = [](void* q) { if (q) (void)hipFree(q); };
         fr(vec_pool); fr(partials); fr(d_rr); fr(d_alpha); fr(d_beta); fr(d_alpha_hist); fr(d_beta_hist);
         fr(d_active); fr(d_iters_tmp); fr(d_nact); fr(d_nonfinite); fr(d_ps); fr(d_hist); fr(d_dxps);
-        fr(d_dxpart); fr(d_hist_ps); fr(d_cg_iters); fr(d_lds_csr); fr(d_m2);
+        fr(d_dxpart); fr(d_hist_ps); fr(d_cg_iters); fr(d_lds_csr); fr(d_m2); fr(d_stop); fr(d_ps2);
+        if (st_side) (void)hipStreamDestroy(st_side);
+        for (auto& e : ev_main) if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_side) if (e) (void)hipEventDestroy(e);
         for (auto& tmd : tmeta) { fr(tmd.tl_col); fr(tmd.tl_w); fr(tmd.halo); fr(tmd.h_rowptr); fr(tmd.h_col); fr(tmd.h_val); }
         fr(cldr_dev.n0); fr(cldr_dev.nC); fr(cldr_dev.rows); fr(cldr_dev.dcol); fr(cldr_dev.dcnt); fr(cldr_dev.tcol); fr(cldr_dev.tcnt);
         fr(cldr_dev.dw); fr(cldr_dev.tw);
@@ -408,6 +418,7 @@ struct Engine : EngineBase {
         if (const char* e = getenv("MGADMM_FOLD_LU")) use_fold_lu = atoi(e);
         if (const char* e = getenv("MGADMM_SWEEP_REV")) sweep_rev = atoi(e);
         if (const char* e = getenv("MGADMM_CLDR_ORDER")) cldr_tile_major = atoi(e);
+        if (const char* e = getenv("MGADMM_LDS_ASYNC")) lds_async = atoi(e);
         Geom q = make_geom(Bmax);
         Bp_max = q.Bp;
         // Bp for smaller batches never exceeds Bp_max rounded to 256
@@ -1443,6 +1454,20 @@ struct Engine : EngineBase {
         MG_HIP(hipMalloc(&d_lds_csr, sizeof(int) * off));
         MG_HIP(hipMemcpy(d_lds_csr, img.data(), sizeof(int) * off, hipMemcpyHostToDevice));
         MG_HIP(hipMalloc(&d_m2, sizeof(double) * T * N * (1 + (size_t)(Bmax + 63) / 64)));
+        MG_HIP(hipMalloc(&d_stop, sizeof(int)));
+        MG_HIP(hipMemset(d_stop, 0, sizeof(int)));
+        MG_HIP(hipMalloc(&d_ps2, sizeof(double) * MGADMM_NMETRIC * Bp_max));
+        {
+            // helper stream of the overlapped outer loop: non-blocking (the caller's stream may be the legacy default stream,
+            // which would serialise a blocking stream with itself), lowest priority (the k_admm_lds workgroups of the next
+            // iteration take the CUs first; the one-wave workgroups of the metric kernels fill the room they leave)
+            int lo = 0, hi = 0;
+            MG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            if (const char* e = getenv("MGADMM_LDS_SIDE_PRIO")) lo = atoi(e) > 0 ? hi : lo;
+            MG_HIP(hipStreamCreateWithPriority(&st_side, hipStreamNonBlocking, lo));
+            for (auto& e : ev_main) MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto& e : ev_side) MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         lds.ok = true;
         return MGADMM_OK;
     }
@@ -1479,13 +1504,32 @@ struct Engine : EngineBase {
             MG_HIP(hipMemsetAsync(d_nonfinite, 0, sizeof(int), st));
             MG_HIP(hipMemsetAsync(d_ps, 0, sizeof(double) * MGADMM_NMETRIC * Bp, st));
             MG_HIP(hipMemsetAsync(d_cg_iters, 0, sizeof(int) * (size_t)max_it * 3 * Bp, st));
+            // Schedule of the outer loop (ADMM.py:546-646 is one loop with the stop test at its end):
+            //   SYNC     (MGADMM_LDS_ASYNC=0, or the CG coefficients are recorded: the host copies them out per iteration)
+            //            one stream, the host reads the metrics of an iteration and tests the stop criterion before it enqueues the next;
+            //   DEVSTOP  (check_stop) one stream, the stop test runs on the device (k_lds_stop_test sets the stop word, every
+            //            later launch returns at its guard), the host enqueues iterations ahead and looks at the word LAG
+            //            iterations late: same iterates and history, no host round trip per iteration;
+            //   OVERLAP  (fixed iteration count) the whole-batch metric kernels of iteration k (delta_x_per_step re-reads x and
+            //            x_old of the batch, 241 MB at cfg2) run on a helper stream beside the k_admm_lds launch of iteration
+            //            k+1, which leaves HBM idle; x rotates through three buffers and the per-sample metric sums through
+            //            two, so that launch k+1 overwrites nothing the metric kernels of iteration k still read; launch k+2
+            //            waits for them.
+            enum { SYNC, DEVSTOP, OVERLAP };
+            const int sched = (!lds_async || record) ? SYNC : (p.check_stop ? DEVSTOP : OVERLAP);
             // The caller's output buffers ARE the working state of this path (same (B, T*N) layout): no copy-out at the end
-            // (round 2 until here: seven 120 MB device copies per solve at cfg2 = 0.7 ms of a 59 ms solve).  x alternates
-            // between two buffers; they are assigned so that the iterate of the LAST iteration lands in x_out (an early
-            // stop on the other parity costs one copy).  Outputs must not alias y / mask (mgadmm.h).
+            // (round 2 until here: seven 120 MB device copies per solve at cfg2 = 0.7 ms of a 59 ms solve).  x rotates
+            // through two (three: OVERLAP) buffers; they are assigned so that the iterate of the LAST iteration lands in
+            // x_out (an early stop on another buffer costs one copy).  Outputs must not alias y / mask (mgadmm.h).
             auto pick = [&](void* out, float* own) { return out ? static_cast<float*>(out) : own; };
             float* const xo_ = static_cast<float*>(x_out);
-            float *xa = (max_it & 1) ? vec[V_XA] : xo_, *xb = (max_it & 1) ? xo_ : vec[V_XA];
+            const int NX = sched == OVERLAP ? 3 : 2;
+            float* X[3] = {nullptr, nullptr, nullptr};      // iteration `it` reads X[it % NX] and writes X[(it + 1) % NX]
+            {
+                float* own[2] = {vec[V_XA], vec[V_XB]};
+                int o = 0;
+                for (int j = 0; j < NX; ++j) X[j] = (j == max_it % NX) ? xo_ : own[o++];
+            }
             float *zu = pick(state_out ? state_out->zu : nullptr, vec[V_ZUA]), *zd = pick(state_out ? state_out->zd : nullptr, vec[V_ZDA]);
             float *phi = pick(state_out && has_phi ? state_out->phi : nullptr, vec[V_PHIA]), *gam = pick(state_out && has_phi ? state_out->gamma : nullptr, vec[V_GAM]);
             float *gu = pick(state_out ? state_out->gamma_u : nullptr, vec[V_GU]), *gd = pick(state_out ? state_out->gamma_d : nullptr, vec[V_GD]);
@@ -1494,7 +1538,7 @@ struct Engine : EngineBase {
                 auto cp = [&](float* dst, const void* src) {
                     return (src == nullptr || dst == src) ? hipSuccess : hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, st);
                 };
-                MG_HIP(cp(xa, x0));
+                MG_HIP(cp(X[0], x0));
                 MG_HIP(cp(zu, state_in->zu));
                 MG_HIP(cp(gu, state_in->gamma_u));
                 MG_HIP(cp(zd, state_in->zd));            // the vectors an ablation does not iterate on are carried through
@@ -1507,7 +1551,7 @@ struct Engine : EngineBase {
                 tm /= (float)p.t_in;
                 t2m /= (float)p.t_in;
                 const float den = t2m - tm * tm;
-                MG_TRY(mg_lds_init(mask != nullptr, T, p.t_in, N, B, tm, den, (const float*)y, (const float*)mask, xa, zu, zd, gam, gu, gd,
+                MG_TRY(mg_lds_init(mask != nullptr, T, p.t_in, N, B, tm, den, (const float*)y, (const float*)mask, X[0], zu, zd, gam, gu, gd,
                                    d_nonfinite, st));
             }
             LdsArgs a{};
@@ -1537,25 +1581,45 @@ struct Engine : EngineBase {
                 a.stagger_ticks = (B >= 2 * ncu && us > 0) ? us * 100 : 0;
             }
             a.y = (const float*)y; a.mask = (const float*)mask;
-            a.ps = d_ps; a.alpha_hist = record ? (float*)d_alpha_hist : nullptr; a.beta_hist = record ? (float*)d_beta_hist : nullptr;
+            a.alpha_hist = record ? (float*)d_alpha_hist : nullptr; a.beta_hist = record ? (float*)d_beta_hist : nullptr;
             a.nonfinite = d_nonfinite;
+            a.stop = sched == DEVSTOP ? d_stop : nullptr;
+            if (sched == DEVSTOP) MG_HIP(hipMemsetAsync(d_stop, 0, sizeof(int), st));
+            if (sched == OVERLAP) MG_HIP(hipMemsetAsync(d_ps2, 0, sizeof(double) * MGADMM_NMETRIC * Bp, st));
             const size_t K = p.max_cg_iter;
             int n_done = 0, rc_final = MGADMM_OK;
-            float *xc = xa, *xn = xb;
+            double* const ps_buf[2] = {d_ps, d_ps2};
+            // the whole-batch metrics of iteration `it` (delta_x_per_step, norms / means over the samples) on stream `s`
+            auto batch_metrics = [&](int it, const double* ps, hipStream_t s) -> int {
+                MG_TRY(mg_lds_dxps(T, N, B, (const float*)X[(it + 1) % NX], (const float*)X[it % NX], d_m2, d_dxps + (size_t)it * T, a.stop, s));
+                hipLaunchKernelGGL(k_batch_metrics, dim3(MGADMM_NMETRIC), dim3(256), 0, s, ps, Bp, B,
+                                   d_hist + (size_t)it * MGADMM_NMETRIC,
+                                   (hist && hist->metrics_per_sample) ? d_hist_ps + (size_t)it * MGADMM_NMETRIC * B : nullptr);
+                MG_HIP(hipGetLastError());
+                return MGADMM_OK;
+            };
             for (int it = 0; it < max_it; ++it) {
                 a.first = it == 0 && !state_in;      // phi = Ldr x0 is formed by the first launch of a cold start
-                a.x_old = xc; a.x_new = xn;
+                a.x_old = X[it % NX]; a.x_new = X[(it + 1) % NX];
                 a.cg_iters = d_cg_iters + (size_t)it * 3 * Bp;
+                a.ps = sched == OVERLAP ? ps_buf[it & 1] : d_ps;
                 if (record) {
                     MG_TRY(fill((S*)d_alpha_hist, 3 * K * Bp, (S)NAN));
                     MG_TRY(fill((S*)d_beta_hist, 3 * K * Bp, (S)NAN));
                 }
+                if (sched == OVERLAP) {
+                    // launch `it` overwrites the x buffer and the metric sums that the metric kernels of iteration it-2 read
+                    if (it >= 2) MG_HIP(hipStreamWaitEvent(st, ev_side[(it - 2) % 3], 0));
+                    MG_TRY(launch_lds(a, B));
+                    MG_HIP(hipEventRecord(ev_main[it % 3], st));
+                    MG_HIP(hipStreamWaitEvent(st_side, ev_main[it % 3], 0));
+                    MG_TRY(batch_metrics(it, a.ps, st_side));
+                    MG_HIP(hipEventRecord(ev_side[it % 3], st_side));
+                    n_done = it + 1;
+                    continue;
+                }
                 MG_TRY(launch_lds(a, B));
-                MG_TRY(mg_lds_dxps(T, N, B, (const float*)xn, (const float*)xc, d_m2, d_dxps + (size_t)it * T, st));
-                hipLaunchKernelGGL(k_batch_metrics, dim3(MGADMM_NMETRIC), dim3(256), 0, st, (const double*)d_ps, Bp, B,
-                                   d_hist + (size_t)it * MGADMM_NMETRIC,
-                                   (hist && hist->metrics_per_sample) ? d_hist_ps + (size_t)it * MGADMM_NMETRIC * B : nullptr);
-                MG_HIP(hipGetLastError());
+                MG_TRY(batch_metrics(it, a.ps, st));
                 if (record) {
                     for (int w = 0; w < 3; ++w) {
                         if (w == 2 && !has_zd) continue;
@@ -1565,9 +1629,16 @@ struct Engine : EngineBase {
                         MG_TRY(fetch_hist(d_beta_hist + (size_t)w * K * Bp, K * Bp, bo, B, Bp, K));
                     }
                 }
-                std::swap(xc, xn);
                 n_done = it + 1;
-                if (p.check_stop) {
+                if (sched == DEVSTOP) {
+                    MG_TRY(mg_lds_stop_test(d_hist + (size_t)it * MGADMM_NMETRIC, d_nonfinite, has_phi, has_zd, p.admm_tol, it, d_stop, st));
+                    MG_HIP(hipMemcpyAsync(h_flag + 1 + it % (LAG + 1), d_stop, sizeof(int), hipMemcpyDeviceToHost, st));
+                    MG_HIP(hipEventRecord(ev_ring[it % (LAG + 1)], st));
+                    if (it >= LAG) {
+                        MG_HIP(hipEventSynchronize(ev_ring[(it - LAG) % (LAG + 1)]));
+                        if (h_flag[1 + (it - LAG) % (LAG + 1)] != 0) break;      // the launches enqueued since returned at their guards
+                    }
+                } else if (p.check_stop) {
                     MG_HIP(hipMemcpyAsync(h_row, d_hist + (size_t)it * MGADMM_NMETRIC, sizeof(double) * MGADMM_NMETRIC,
                                           hipMemcpyDeviceToHost, st));
                     MG_HIP(hipMemcpyAsync(h_flag, d_nonfinite, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1581,6 +1652,18 @@ struct Engine : EngineBase {
                     if (pri < p.admm_tol && dual < p.admm_tol) break;
                 }
             }
+            if (sched == OVERLAP && n_done > 0)        // join the helper stream (its kernels run in order: the last event covers all)
+                MG_HIP(hipStreamWaitEvent(st, ev_side[(n_done - 1) % 3], 0));
+            if (sched == DEVSTOP) {
+                // the stop word after everything enqueued has run: 0 = no stop (all enqueued iterations ran), k > 0 = the stop
+                // test passed at the end of iteration k - 1, k < 0 = iteration -k - 1 met a NaN / Inf
+                MG_HIP(hipMemcpyAsync(h_flag + 1, d_stop, sizeof(int), hipMemcpyDeviceToHost, st));
+                MG_HIP(hipStreamSynchronize(st));
+                const int sw = h_flag[1];
+                if (sw > 0) n_done = sw;
+                else if (sw < 0) { n_done = -sw; rc_final = MGADMM_ERR_NONFINITE; }
+            }
+            float* const xc = X[n_done % NX];
             if (xc != xo_)        // early stop on the other parity
                 MG_HIP(hipMemcpyAsync(x_out, xc, (size_t)B * TN * sizeof(float), hipMemcpyDeviceToDevice, st));
             return finish_history(hist, n_done, B, Bp, rc_final);

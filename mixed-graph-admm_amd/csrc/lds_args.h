@@ -33,6 +33,8 @@ struct LdsArgs {
     float* alpha_hist;     // [3][max_cg][Bp] or nullptr
     float* beta_hist;
     int* nonfinite;
+    const int* stop;       // device stop word of the ADMM outer loop (nullptr: none): a launch enqueued speculatively after the
+                           // stop test of an earlier iteration passed returns at its first instruction
 };
 
 // Execution plan of k_admm_lds chosen by Engine::plan_lds
@@ -50,5 +52,9 @@ int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st
 // initial state in sample-major layout (ADMM.py:528-544)
 int mg_lds_init(bool masked, int T, int t_in, int N, int B, float tm, float den, const float* y, const float* mask, float* x,
                 float* zu, float* zd, float* gam, float* gu, float* gd, int* nonfinite, hipStream_t st);
-// delta_x_per_step on the sample-major layout (ADMM.py:614): scratch = double[TN * (1 + ceil(B/64))], out = double[T]
-int mg_lds_dxps(int T, int N, int B, const float* x, const float* xo, double* scratch, double* out, hipStream_t st);
+// delta_x_per_step on the sample-major layout (ADMM.py:614): scratch = double[TN * (1 + ceil(B/64))], out = double[T];
+// stop: device stop word (the kernels return at once when it is set) or nullptr
+int mg_lds_dxps(int T, int N, int B, const float* x, const float* xo, double* scratch, double* out, const int* stop, hipStream_t st);
+// stop test of one ADMM iteration on the device (ADMM.py:645-646 + the NaN asserts): *stop = it + 1 when both residual maxima
+// are below tol, -(it + 1) when a metric or the iterate is not finite; leaves a stop word that is already set alone
+int mg_lds_stop_test(const double* metrics_row, const int* nonfinite, int has_phi, int has_zd, double tol, int it, int* stop, hipStream_t st);

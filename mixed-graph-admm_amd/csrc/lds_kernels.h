@@ -527,6 +527,9 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     int* csr = reinterpret_cast<int*>(red + 32);
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
+    // ADMM outer loop without host round trips: iterations are enqueued ahead of the host's look at the stop test, a launch
+    // that follows the stopping iteration must leave the state alone (workgroup-uniform scalar load)
+    if (a.stop != nullptr && *a.stop != 0) return;
     // diagnostic build (make EXTRA=-DMGADMM_PHASE_CLOCK): the per-sample metric slots receive the 100 MHz clock at the
     // phase boundaries instead of the metrics (tools/lds_phase_clock.py)
     auto stamp = [&](int m) {
@@ -941,9 +944,9 @@ __global__ __launch_bounds__(256) void k_init_lds(int T, int t_in, int N, int B,
 // delta_x_per_step on the sample-major layout.  Pass 1: workgroup (e-block, b-slice) sums x - x_old over
 // its 64 samples -> part[slice][e].  Pass 2: fixed-order sum over the slices, mean, square -> m2[e].
 __global__ __launch_bounds__(256) void k_dxps_sm(int TN, int B, const float* __restrict__ x, const float* __restrict__ xo,
-                                                 double* __restrict__ part) {
+                                                 double* __restrict__ part, const int* __restrict__ stop) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= TN) return;
+    if (e >= TN || (stop != nullptr && *stop != 0)) return;
     const int b0 = blockIdx.y * 64, b1 = min(B, b0 + 64);
     double s = 0.0;
     for (int b = b0; b < b1; ++b) s += (double)x[(size_t)b * TN + e] - (double)xo[(size_t)b * TN + e];
@@ -952,10 +955,13 @@ __global__ __launch_bounds__(256) void k_dxps_sm(int TN, int B, const float* __r
 
 // the same with four consecutive elements per thread (16-byte loads; T*N a multiple of 4 and 16-byte aligned vectors):
 // 61 -> 4x fewer load instructions for the 2 * B * T*N * 4 bytes this pass streams
-__global__ __launch_bounds__(256) void k_dxps_sm4(int TN, int B, const float* __restrict__ x, const float* __restrict__ xo,
-                                                  double* __restrict__ part) {
-    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e >= TN) return;
+// One-wave workgroups: in the overlapped schedule of the outer loop (Engine::solve_lds) this kernel runs beside the k_admm_lds
+// launch of the next iteration, whose workgroup leaves room for single waves only (its 15 waves fill three of the four SIMDs
+// of a CU; the fourth has 128 free VGPRs)
+__global__ __launch_bounds__(64) void k_dxps_sm4(int TN, int B, const float* __restrict__ x, const float* __restrict__ xo,
+                                                 double* __restrict__ part, const int* __restrict__ stop) {
+    const int e = (blockIdx.x * 64 + threadIdx.x) * 4;
+    if (e >= TN || (stop != nullptr && *stop != 0)) return;
     const int b0 = blockIdx.y * 64, b1 = min(B, b0 + 64);
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int b = b0;
@@ -987,9 +993,9 @@ __global__ __launch_bounds__(256) void k_dxps_sm4(int TN, int B, const float* __
 }
 
 __global__ __launch_bounds__(256) void k_dxps_sm_mean(int TN, int B, int nslices, const double* __restrict__ part,
-                                                      double* __restrict__ m2) {
+                                                      double* __restrict__ m2, const int* __restrict__ stop) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= TN) return;
+    if (e >= TN || (stop != nullptr && *stop != 0)) return;
     double s = 0.0;
     int k = 0;
     for (; k + 8 <= nslices; k += 8) {        // eight slices per trip in flight (one per trip: 64 dependent L2 round trips, 17 us); same order of additions
@@ -1004,8 +1010,9 @@ __global__ __launch_bounds__(256) void k_dxps_sm_mean(int TN, int B, int nslices
     m2[e] = s * s;
 }
 
-__global__ void k_dxps_sm_final(int T, int N, const double* __restrict__ m2, double* __restrict__ out) {
+__global__ void k_dxps_sm_final(int T, int N, const double* __restrict__ m2, double* __restrict__ out, const int* __restrict__ stop) {
     const int t = blockIdx.x;
+    if (stop != nullptr && *stop != 0) return;          // uniform
     __shared__ double sm[256];
     double s = 0.0;
     for (int i = threadIdx.x; i < N; i += 256) s += m2[(size_t)t * N + i];
@@ -1016,4 +1023,18 @@ __global__ void k_dxps_sm_final(int T, int N, const double* __restrict__ m2, dou
         __syncthreads();
     }
     if (threadIdx.x == 0) out[t] = sqrt(sm[0]);
+}
+
+// Stop test of one ADMM iteration, on the device (the host's test of the synchronous loop, Engine::solve_lds): row = the
+// whole-batch metrics of iteration `it` (k_batch_metrics).  One lane.
+__global__ void k_lds_stop_test(const double* __restrict__ row, const int* __restrict__ nonfinite, int has_phi, int has_zd, double tol,
+                                int it, int* __restrict__ stop) {
+    if (threadIdx.x != 0 || *stop != 0) return;
+    bool finite = *nonfinite == 0;
+    for (int k = 0; k < MGADMM_NMETRIC; ++k) finite = finite && (fabs(row[k]) <= 1.7976931348623157e308);
+    if (!finite) { *stop = -(it + 1); return; }
+    double pri = row[MGADMM_M_PRI_ZU], dual = row[MGADMM_M_DUAL_ZU];
+    if (has_phi) { pri = fmax(pri, row[MGADMM_M_PRI_PHI]); dual = fmax(dual, row[MGADMM_M_DUAL_PHI]); }
+    if (has_zd) { pri = fmax(pri, row[MGADMM_M_PRI_ZD]); dual = fmax(dual, row[MGADMM_M_DUAL_ZD]); }
+    if (pri < tol && dual < tol) *stop = it + 1;
 }

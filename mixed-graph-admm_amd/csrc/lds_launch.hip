@@ -70,14 +70,20 @@ int mg_lds_init(bool masked, int T, int t_in, int N, int B, float tm, float den,
     return MGADMM_OK;
 }
 
-int mg_lds_dxps(int T, int N, int B, const float* x, const float* xo, double* scratch, double* out, hipStream_t st) {
+int mg_lds_dxps(int T, int N, int B, const float* x, const float* xo, double* scratch, double* out, const int* stop, hipStream_t st) {
     const int TN = T * N, nsl = (B + 63) / 64;
     if (TN % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)xo % 16) == 0)
-        hipLaunchKernelGGL(k_dxps_sm4, dim3((TN / 4 + 255) / 256, nsl), dim3(256), 0, st, TN, B, x, xo, scratch + TN);
+        hipLaunchKernelGGL(k_dxps_sm4, dim3((TN / 4 + 63) / 64, nsl), dim3(64), 0, st, TN, B, x, xo, scratch + TN, stop);
     else
-        hipLaunchKernelGGL(k_dxps_sm, dim3((TN + 255) / 256, nsl), dim3(256), 0, st, TN, B, x, xo, scratch + TN);
-    hipLaunchKernelGGL(k_dxps_sm_mean, dim3((TN + 255) / 256), dim3(256), 0, st, TN, B, nsl, (const double*)(scratch + TN), scratch);
-    hipLaunchKernelGGL(k_dxps_sm_final, dim3(T), dim3(256), 0, st, T, N, (const double*)scratch, out);
+        hipLaunchKernelGGL(k_dxps_sm, dim3((TN + 255) / 256, nsl), dim3(256), 0, st, TN, B, x, xo, scratch + TN, stop);
+    hipLaunchKernelGGL(k_dxps_sm_mean, dim3((TN + 255) / 256), dim3(256), 0, st, TN, B, nsl, (const double*)(scratch + TN), scratch, stop);
+    hipLaunchKernelGGL(k_dxps_sm_final, dim3(T), dim3(256), 0, st, T, N, (const double*)scratch, out, stop);
+    MG_HIP(hipGetLastError());
+    return MGADMM_OK;
+}
+
+int mg_lds_stop_test(const double* metrics_row, const int* nonfinite, int has_phi, int has_zd, double tol, int it, int* stop, hipStream_t st) {
+    hipLaunchKernelGGL(k_lds_stop_test, dim3(1), dim3(64), 0, st, metrics_row, nonfinite, has_phi, has_zd, tol, it, stop);
     MG_HIP(hipGetLastError());
     return MGADMM_OK;
 }
