@@ -390,14 +390,51 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, c
 #pragma unroll
     for (int k = 0; k < TPG; ++k) l[k] = 0.f;
     if (KIND == 1) {
-        float q[TPG];
+        if constexpr (BAND) {
+            float q[TPG];
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) q[k] = 0.f;
-        if (c.active) c.op_ldr(c.P, v, q, PRE);
-        if (SB) __syncthreads();           // single LDS vector (Q aliases P): every gather of p is done before q replaces it
-        c.template put<+1, EDGE || SB>(c.Q, q);      // SB: p and q alternate in one vector, their zero slots included
-        __syncthreads();
-        if (c.active) c.op_ldrt(c.Q, q, l, PRET);
+            for (int k = 0; k < TPG; ++k) q[k] = 0.f;
+            if (c.active) c.op_ldr(c.P, v, q, PRE);
+            if (SB) __syncthreads();           // single LDS vector (Q aliases P): every gather of p is done before q replaces it
+            c.template put<+1, EDGE || SB>(c.Q, q);      // SB: p and q alternate in one vector, their zero slots included
+            __syncthreads();
+            if (c.active) c.op_ldrt(c.Q, q, l, PRET);
+        } else {
+            // SHIFTED OWNERSHIP of q = Ldr v.  Ldr reads time t-1 and Ldr^T time t+1, so with one partition of the time axis for
+            // both vectors either the store or the gather of an image is off by one float against the 16-byte groups (until
+            // mid round 2 the images were stored shifted: one ds_write_b128 + four scalar ds_write_b32 per store, the scalar
+            // stores of 32 consecutive nodes on 8 banks).  Here the thread that owns v at times t0 .. t0+TPG-1 computes and owns
+            // q at times t0+1 .. t0+TPG: its gather for q[t0+1+k] is the aligned run v[col][t0+k] of the UNSHIFTED image of v,
+            // it stores its q values as the aligned run at positions t0 .. (position j of the q image holds q[j+1]; time T
+            // does not exist: 0), and the Ldr^T gather for time t0+k reads q[col][t0+k+1] = that aligned run again.  Both
+            // images go out as whole ds_write_b128, every gather is an aligned run; the price is one scalar read per
+            // operator for the self term that sits in the neighbouring time group (v[t0+TPG] resp. q[t0]).  Same products in
+            // the same order: bitwise the former results.
+            float q[TPG];        // q[k] = (Ldr v)[t0 + k + 1]
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) q[k] = 0.f;
+            if (c.active) {
+                float acc[TPG];
+                if constexpr (ND > 0) c.template gather_fixed<ND>(c.P, c.en_d, c.d0, acc, PRE);
+                else c.gather(c.P, c.en_d, c.d0, c.d1, acc);
+                const bool has_next = c.t0 + TPG < c.T;
+                const float vnext = has_next ? c.P[c.own() + TPG] : 0.f;        // v at the first time of the next group, own node
+#pragma unroll
+                for (int k = 0; k + 1 < TPG; ++k) q[k] = v[k + 1] - acc[k];
+                q[TPG - 1] = has_next ? vnext - acc[TPG - 1] : 0.f;
+            }
+            if (SB) __syncthreads();           // single LDS vector (Q aliases P): every gather of p is done before q replaces it
+            if (c.active) lds_store<TPG>(c.Q + c.own(), q);
+            __syncthreads();
+            if (c.active) {
+                float acc[TPG];
+                c.template gather_lead<LDS_NLEAD>(c.Q, c.en_t, c.t0e, c.t1e, acc, PRET);
+                const float qprev = c.t0 > 0 ? c.Q[c.own() - 1] : 0.f;          // q[t0]: the last value of the previous group (q[0] = 0)
+                l[0] = qprev - acc[0];
+#pragma unroll
+                for (int k = 1; k < TPG; ++k) l[k] = q[k - 1] - acc[k];
+            }
+        }
     } else if (KIND == 2) {
         if (c.active) c.op_lu(c.P, v, l, PRE);
     }
@@ -428,7 +465,7 @@ template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND>
 __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
                       int hth, int t_in, float c1, float c2, int max_cg, double tol, float* ah, float* bh, int Bp,
                       int* nonfinite) {
-    constexpr int SHP = KIND == 1 ? -1 : 0;     // the image of the CG direction: read by Ldr (cLdr solves) or by Lu
+    constexpr int SHP = 0;     // the image of the CG direction is stored unshifted for every operator (lds_apply: shifted ownership of q)
     float r[TPG], pv[TPG], av[TPG], dc[TPG];
     c.template put<SHP>(c.P, x);
     __syncthreads();
