@@ -14,6 +14,7 @@
 #include "cldr_tiles.h"
 #include "stream_kernels.h"
 #include "lds_args.h"
+#include "lds_banks.h"
 
 namespace {
 
@@ -1369,87 +1370,50 @@ struct Engine : EngineBase {
         lds.maxt = (best == 12 && lds.block <= 640) ? 640 : 1024;
         if (lds.sb && !((best == 12 && lds.maxt == 640) || best == 8)) lds.sb = 0;
         std::vector<int> img(off, 0);
-        // Bank-aware entry order.  A gather instruction reads entry e of 64 consecutive threads' rows (64 consecutive
-        // nodes, mostly); ds_read_b128 serves it in four groups of 16 lanes, and two lanes of a group collide when their
-        // neighbour rows start in the same 16-byte slot of the 256-byte bank line: slot = (TS/4 * col + const) mod 16,
-        // i.e. when col_a = col_b mod 16 for different columns (TS/4 is odd).  WHICH neighbour sits in entry e of a row is
-        // free: rows are taken in node order and every row picks the permutation of its entries that collides least with
-        // the rows already placed in its lane groups (all permutations up to 5 entries, the offset-sorted order and random
-        // shuffles beyond).  Round 1 kept the table order: 36 % of the LDS cycles of k_admm_lds were bank conflicts.
-        // The sum of a row then runs in the chosen order (fixed per graph: bitwise repeatable).
+        // Bank-aware entry order (lds_banks.h).  A gather instruction reads entry e of 64 consecutive threads' rows (64
+        // consecutive nodes, mostly); ds_read_b128 serves it in four groups of 16 lanes, and two lanes of a group collide
+        // when their neighbour rows start in the same 16-byte slot of the 256-byte bank line.  WHICH neighbour sits in entry
+        // e of a row is free.  Round 1 kept the table order (36 % of the LDS cycles of k_admm_lds were bank conflicts); round 2
+        // a greedy order, rows in node order (20 % -- and a timing build with conflict-free gathers showed that those 20 %
+        // cost 18 % of the launch); now the greedy order is the start of a min-conflicts search against an exact replay
+        // of the kernel's read stream (ldsbank::improve_targeted): cfg2 goes from 7 800 to 1 200 weighted conflict cycles
+        // in 0.15 s of host time per solver.  The sum of a row runs in the chosen order (fixed per graph: repeatable).
+        // MGADMM_LDS_TABLE_ORDER=1 keeps the table order, MGADMM_LDS_BANK_SEARCH=<steps> sets the search length (0: greedy only).
         const bool bank_order = !band && best % 4 == 0 && ((lds.TS / 4) & 1) && !getenv("MGADMM_LDS_TABLE_ORDER");
-        auto slot_order = [&](const HostCsr& h) {
+        long search_steps = 1500;
+        if (const char* e = getenv("MGADMM_LDS_BANK_SEARCH")) search_steps = atol(e);
+        auto slot_order = [&](const HostCsr& h, ldsbank::Stream stream) {
             std::vector<int> order(h.nnz());
             for (int e = 0; e < h.nnz(); ++e) order[e] = e;
-            if (!bank_order) return order;
-            static const int grp_of_lane[32] = {0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
-            const int G = T / best;
-            int maxlen = 0;
-            for (int i = 0; i < N; ++i) maxlen = std::max(maxlen, h.rowptr[i + 1] - h.rowptr[i]);
-            const int nwaves = (N * G + 63) / 64;
-            // used[(wave*4 + group)*maxlen + e][colour] = column that occupies the colour (-1 free, -2 several)
-            std::vector<int> used((size_t)nwaves * 4 * maxlen * 16, -1);
-            unsigned rng = 12345u;
-            auto rnd = [&]() { rng = rng * 1664525u + 1013904223u; return rng >> 8; };
-            for (int i = 0; i < N; ++i) {
-                const int e0 = h.rowptr[i], len = h.rowptr[i + 1] - e0;
-                if (len <= 1) continue;
-                int keys[16];                                       // lane groups this node's threads (one per time group) sit in
-                for (int gq = 0; gq < G; ++gq) {
-                    const int tid = i + N * gq, lane = tid & 63;
-                    keys[gq] = (tid >> 6) * 4 + (lane >> 5) * 2 + grp_of_lane[lane & 31];
-                }
-                auto cost = [&](const std::vector<int>& perm) {
-                    int c = 0;
-                    for (int e = 0; e < len; ++e) {
-                        const int col = h.col[e0 + perm[e]], colour = col & 15;
-                        for (int gq = 0; gq < G; ++gq) {
-                            const int u = used[((size_t)keys[gq] * maxlen + e) * 16 + colour];
-                            if (u != -1 && u != col) ++c;
-                        }
-                    }
-                    return c;
-                };
-                std::vector<int> perm(len), bestp;
-                for (int e = 0; e < len; ++e) perm[e] = e;
-                int bc = 1 << 30;
-                if (len <= 5) {
-                    do {
-                        const int c = cost(perm);
-                        if (c < bc) { bc = c; bestp = perm; }
-                    } while (bc > 0 && std::next_permutation(perm.begin(), perm.end()));
-                } else {
-                    std::vector<int> p2 = perm;
-                    std::stable_sort(p2.begin(), p2.end(), [&](int a, int b) { return h.col[e0 + a] - i < h.col[e0 + b] - i; });
-                    for (int trial = 0; trial < 300 && bc > 0; ++trial) {
-                        const int c = cost(p2);
-                        if (c < bc) { bc = c; bestp = p2; }
-                        for (int e = len - 1; e > 0; --e) std::swap(p2[e], p2[rnd() % (e + 1)]);
-                    }
-                }
-                for (int e = 0; e < len; ++e) {
-                    order[e0 + e] = e0 + bestp[e];
-                    const int col = h.col[e0 + bestp[e]], colour = col & 15;
-                    for (int gq = 0; gq < G; ++gq) {
-                        int& u = used[((size_t)keys[gq] * maxlen + e) * 16 + colour];
-                        u = (u == -1 || u == col) ? col : -2;
-                    }
-                }
+            if (!bank_order || h.nnz() == 0) return order;
+            ldsbank::Geometry q;
+            q.N = N; q.G = T / best; q.TPG = best; q.TS = lds.TS; q.nlead = LDS_NLEAD;
+            ldsbank::Mat m;
+            m.rowptr = h.rowptr; m.col = h.col; m.src = order; m.stream = stream;
+            ldsbank::greedy_order(q, m);
+            if (search_steps > 0) {
+                std::vector<int> pos(N);
+                for (int i = 0; i < N; ++i) pos[i] = i;
+                const ldsbank::Result r = ldsbank::improve_targeted(q, m, pos, search_steps);
+                if (getenv("MGADMM_LDS_BANK_STATS"))
+                    fprintf(stderr, "[mgadmm] lds bank search: stream %d, %d entries: %.0f -> %.0f conflict cycles per application (%ld steps)\n",
+                            (int)stream, h.nnz(), r.before, r.after, r.moves);
             }
-            return order;
+            return m.src;
         };
-        auto put_csr = [&](const HostCsr& h, int off_rp, int off_en) {
-            const std::vector<int> order = slot_order(h);
+        auto put_csr = [&](const HostCsr& h, int off_rp, int off_en, ldsbank::Stream stream) {
+            const std::vector<int> order = slot_order(h, stream);
             for (int i = 0; i <= N; ++i) img[off_rp + i] = h.rowptr[i];
             for (int e = 0; e < h.nnz(); ++e) {
                 img[off_en + 2 * e] = h.col[order[e]] * lds.TS;       // LDS float offset of the neighbour's time row
                 memcpy(&img[off_en + 2 * e + 1], &h.val[order[e]], 4);
             }
         };
-        put_csr(g->hWu, lds.off_rp_u, lds.off_en_u);
+        const ldsbank::Stream fixed_or_pairs = lds.uniform45 ? ldsbank::FIXED : ldsbank::PAIRS;     // gather_fixed / gather
+        put_csr(g->hWu, lds.off_rp_u, lds.off_en_u, fixed_or_pairs);
         if (!band) {
-            put_csr(g->hWd, lds.off_rp_d, lds.off_en_d);
-            put_csr(g->hWdT, lds.off_rp_t, lds.off_en_t);
+            put_csr(g->hWd, lds.off_rp_d, lds.off_en_d, fixed_or_pairs);
+            put_csr(g->hWdT, lds.off_rp_t, lds.off_en_t, ldsbank::LEAD_PAIRS);      // gather_lead
         }
         MG_HIP(hipMalloc(&d_lds_csr, sizeof(int) * off));
         MG_HIP(hipMemcpy(d_lds_csr, img.data(), sizeof(int) * off, hipMemcpyHostToDevice));

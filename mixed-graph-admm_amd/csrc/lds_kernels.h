@@ -129,6 +129,17 @@ __device__ __forceinline__ void lds_store(float* p, const float (&v)[TPG]) {
 __device__ __forceinline__ float ldg(const float* base, unsigned boff) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
 }
+// knock-out timing build MGADMM_KO_OWNROW: every gather reads the thread's OWN row instead of the neighbour's (consecutive
+// nodes -> distinct 16-byte slots: no bank conflict) -- same instruction stream, wrong results, tells what the conflicts cost
+// MGADMM_KO_CIRC: entry number u of every row reads node (i + u) mod N -- distinct rows per entry, consecutive nodes per
+// lane group: conflict-free under the bank model of lds_banks.h without the identical addresses of KO_OWNROW
+#if defined(MGADMM_KO_OWNROW)
+#define MG_ENX(x, u) (i * TS)
+#elif defined(MGADMM_KO_CIRC)
+#define MG_ENX(x, u) (((i + (u)) % N) * TS)
+#else
+#define MG_ENX(x, u) (x)
+#endif
 // REQUEST fence: the loads before it are issued together and waited for together, nothing crosses it.
 #define MG_REQ_FENCE() asm volatile("" ::: "memory")
 
@@ -174,8 +185,8 @@ struct LdsCtx {
         for (; e + 1 < e1; e += 2) {
             const int2 ea = na, eb = nb;
             float va[TPG], vb[TPG];
-            lds_load<TPG>(base + ea.x, va);
-            lds_load<TPG>(base + eb.x, vb);
+            lds_load<TPG>(base + MG_ENX(ea.x, e - e0), va);
+            lds_load<TPG>(base + MG_ENX(eb.x, e - e0 + 1), vb);
             na = EN[e + 2];
             nb = EN[e + 3];
             const float wa = __int_as_float(ea.y), wb = __int_as_float(eb.y);
@@ -186,7 +197,7 @@ struct LdsCtx {
         }
         if (e < e1) {
             float va[TPG];
-            lds_load<TPG>(base + na.x, va);
+            lds_load<TPG>(base + MG_ENX(na.x, e - e0), va);
             const float wa = __int_as_float(na.y);
 #pragma unroll
             for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
@@ -211,8 +222,8 @@ struct LdsCtx {
 #pragma unroll
         for (int u = 0; u + 1 < NFIX; u += 2) {
             float va[TPG], vb[TPG];
-            lds_load<TPG>(base + en[u].x, va);
-            lds_load<TPG>(base + en[u + 1].x, vb);
+            lds_load<TPG>(base + MG_ENX(en[u].x, u), va);
+            lds_load<TPG>(base + MG_ENX(en[u + 1].x, u + 1), vb);
             const float wa = __int_as_float(en[u].y), wb = __int_as_float(en[u + 1].y);
 #pragma unroll
             for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
@@ -221,7 +232,7 @@ struct LdsCtx {
         }
         if (NFIX & 1) {
             float va[TPG];
-            lds_load<TPG>(base + en[NFIX - 1].x, va);
+            lds_load<TPG>(base + MG_ENX(en[NFIX - 1].x, NFIX - 1), va);
             const float wa = __int_as_float(en[NFIX - 1].y);
 #pragma unroll
             for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
@@ -247,8 +258,8 @@ struct LdsCtx {
 #pragma unroll
         for (int u = 0; u < NLEAD; u += 2) {
             float va[TPG], vb[TPG];
-            lds_load<TPG>(base + en[u].x, va);
-            if (u + 1 < NLEAD) lds_load<TPG>(base + en[u + 1].x, vb);
+            lds_load<TPG>(base + MG_ENX(en[u].x, u), va);
+            if (u + 1 < NLEAD) lds_load<TPG>(base + MG_ENX(en[u + 1].x, u + 1), vb);
             const float wa = u < len ? __int_as_float(en[u].y) : 0.f;
 #pragma unroll
             for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
@@ -264,8 +275,8 @@ struct LdsCtx {
             for (; e + 1 < e1; e += 2) {
                 const int2 ea = na, eb = nb;
                 float va[TPG], vb[TPG];
-                lds_load<TPG>(base + ea.x, va);
-                lds_load<TPG>(base + eb.x, vb);
+                lds_load<TPG>(base + MG_ENX(ea.x, e - e0), va);
+                lds_load<TPG>(base + MG_ENX(eb.x, e - e0 + 1), vb);
                 na = EN[e + 2];
                 nb = EN[e + 3];
                 const float wa = __int_as_float(ea.y), wb = __int_as_float(eb.y);
@@ -276,7 +287,7 @@ struct LdsCtx {
             }
             if (e < e1) {
                 float va[TPG];
-                lds_load<TPG>(base + na.x, va);
+                lds_load<TPG>(base + MG_ENX(na.x, e - e0), va);
                 const float wa = __int_as_float(na.y);
 #pragma unroll
                 for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
@@ -418,7 +429,13 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, c
                 if constexpr (ND > 0) c.template gather_fixed<ND>(c.P, c.en_d, c.d0, acc, PRE);
                 else c.gather(c.P, c.en_d, c.d0, c.d1, acc);
                 const bool has_next = c.t0 + TPG < c.T;
-                const float vnext = has_next ? c.P[c.own() + TPG] : 0.f;        // v at the first time of the next group, own node
+                // v at the first time of the next group, own node: taken from its aligned 16-byte group (a scalar read of the
+                // same column of 32 consecutive rows is a 4-way bank conflict, the ds_read_b128 of consecutive rows none)
+                float vnext = 0.f;
+                if (has_next) {
+                    if constexpr (TPG % 4 == 0) vnext = static_cast<const lds_f4*>(__builtin_assume_aligned(c.P + c.own() + TPG, 16))[0].x;
+                    else vnext = c.P[c.own() + TPG];
+                }
 #pragma unroll
                 for (int k = 0; k + 1 < TPG; ++k) q[k] = v[k + 1] - acc[k];
                 q[TPG - 1] = has_next ? vnext - acc[TPG - 1] : 0.f;
@@ -429,7 +446,11 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, c
             if (c.active) {
                 float acc[TPG];
                 c.template gather_lead<LDS_NLEAD>(c.Q, c.en_t, c.t0e, c.t1e, acc, PRET);
-                const float qprev = c.t0 > 0 ? c.Q[c.own() - 1] : 0.f;          // q[t0]: the last value of the previous group (q[0] = 0)
+                float qprev = 0.f;          // q[t0]: the last value of the previous group (q[0] = 0), from its aligned 16-byte group
+                if (c.t0 > 0) {
+                    if constexpr (TPG % 4 == 0) qprev = static_cast<const lds_f4*>(__builtin_assume_aligned(c.Q + c.own() - 4, 16))[0].w;
+                    else qprev = c.Q[c.own() - 1];
+                }
                 l[0] = qprev - acc[0];
 #pragma unroll
                 for (int k = 1; k < TPG; ++k) l[k] = q[k - 1] - acc[k];
