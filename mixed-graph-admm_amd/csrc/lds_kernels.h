@@ -269,7 +269,15 @@ struct LdsCtx {
                 for (int k = 0; k < TPG; ++k) acc[k] += wb * vb[k];
             }
         }
+        // (knock-out timing build MGADMM_KO_NOTAIL: rows cut after the leading entries -- this tail, a tenth of the gathers, costs a
+        // fifth of the cfg2 launch: every wave holds a 9- or 10-entry row and runs three dependent trips.  Measured and not
+        // kept: a second batch of four entries gathered like the leading ones -- 220 B of scratch, +18 %; the first pair of
+        // entries requested ahead of the leading rows -- no change)
+#ifdef MGADMM_KO_NOTAIL
+        if (false) {
+#else
         if (len > NLEAD) {
+#endif
             int e = e0 + NLEAD;
             int2 na = EN[e], nb = EN[e + 1];
             for (; e + 1 < e1; e += 2) {
