@@ -129,3 +129,26 @@ def test_nonfinite_input_is_reported_by_both_schedules():
                 blk.close()
             finally:
                 os.environ.pop("MGADMM_LDS_ASYNC", None)
+
+
+def test_overlapped_schedule_on_a_side_stream_of_the_caller():
+    """The ABI takes the caller's stream: the helper stream of the overlapped schedule is ordered against it with events, also
+    when it is not the default stream; the result is bitwise the default-stream result."""
+    meta = load_golden("g4_meta.npz")
+    y, _ = case_inputs(meta, "pred", np.float32)
+    y = np.concatenate([y * (1 + 0.01 * r) for r in range(100)])
+    blk = make_product(meta, "knn", path="lds")
+    blk.check_stop = False
+    blk.max_ADMM_iter = 8
+    yt = torch.from_numpy(y).cuda()
+    x0 = blk.combined_loop(yt, print_info=False).clone()
+    h0 = np.array(blk.p_res_list)
+    blk._reset_history()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        x1 = blk.combined_loop(yt, print_info=False)
+    s.synchronize()
+    assert torch.equal(x0, x1)
+    np.testing.assert_array_equal(h0, np.array(blk.p_res_list))
+    blk.close()
