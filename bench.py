@@ -9,6 +9,8 @@ A "step" is one ADMM iteration (3 batched CG solves + prox + dual updates + resi
 reference ADMM.py:546-646) over the whole batch resident in HBM.  The timed region is ONE solve of
 exactly K iterations (no early stop), including its small set-up (layout pack, initial guess) and the
 final unpack / gather, bracketed by barrier + torch.cuda.synchronize(); the time is the MAX over ranks.
+With N > 1 the only exchange of the path -- the gather of the x shards to rank 0 -- is inside the timed region; with
+--gather-chunks c a rank solves its block as c sub-blocks and the asynchronous gather of one overlaps the solve of the next.
 
 Workloads (BASELINE.json configs; synthetic data, seeds fixed):
   cfg2 (default) PEMS04-shaped graph: N=307, 340 undirected edges, k=4, B=4096 windows per GPU, fp32
@@ -270,6 +272,11 @@ def main():
     ap.add_argument("--no-cfg3-leg", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
+    ap.add_argument("--gather-chunks", type=int, default=0,
+                    help="N > 1: sub-blocks per rank; the final gather of one overlaps the solve of the next "
+                         "(default 1: two half-batch solves cost 3.7 %% more than one at cfg2 -- 1.585 vs 1.646 M "
+                         "sample-iterations/s, fixed per-solve work -- which is more than the overlap hides of a 120 MB/rank "
+                         "gather; the streaming workloads would also drop to a narrower vector width)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -303,17 +310,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1: the rank's block is solved as `chunks` sub-blocks one after the other (samples are independent: the same
+    # iterates, mgadmm.dist.sharded_solve(chunks=) does the same); the gather of sub-block c is issued asynchronously
+    # (RCCL runs it on its own stream) and overlaps the solve of sub-block c+1, so only the last sub-block's share of the
+    # exchange is exposed.  N = 1 has no exchange and solves its block in one piece.  Default: one piece everywhere.
+    chunks = args.gather_chunks or 1
+    chunks = max(1, min(chunks, B)) if world > 1 else 1
+    Bc = (B + chunks - 1) // chunks
+
     def run(iters, prof):
         blk.max_ADMM_iter = iters
         blk._reset_history()
         if prof:
             blk.prof_begin()
-        x = blk.combined_loop(y, print_info=False)
-        gathered = None
-        if world > 1:                       # the only exchange of the path: final gather of the x shards (RCCL/xGMI)
+        if world == 1:
+            return blk.combined_loop(y, print_info=False), None
+        pending, x = [], None
+        for c in range(chunks):             # the only exchange of the path: final gather of the x shards (RCCL/xGMI)
+            a, b = c * Bc, min(B, (c + 1) * Bc)
+            x = blk.combined_loop(y[a:b], print_info=False)
             xs = x.to(cdev)
             gathered = [torch.empty_like(xs) for _ in range(world)] if rank == 0 else None
-            dist.gather(xs, gathered, dst=0)
+            work = dist.gather(xs, gathered, dst=0, async_op=c + 1 < chunks)
+            pending.append((xs, gathered, work))      # the buffers stay referenced until the exchange has completed
+        for _, _, work in pending:
+            if work is not None:
+                work.wait()
         return x, None
 
     # warm-up (untimed): creates the solver workspace and the HIP event pool, pages kernels in
@@ -350,13 +372,15 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}", "batch_per_gpu": B, "global_batch": world * B,
                        "ablation": "None", "graph": "kNN-directed", "cg_tol": 1e-8, "max_cg_iter": 100,
-                       "parallelism": f"batch-sharded x{world}, no collective on the convergence path, final RCCL gather",
+                       "parallelism": f"batch-sharded x{world}, no collective on the convergence path, final RCCL gather"
+                                      + (f" in {chunks} sub-blocks (all but the last overlap the next sub-block's solve)"
+                                         if world > 1 else ""),
                        "mean_cg_iters": cg_counts, "solver_path": path, "all_finite": finite,
                        "workspace_GB": blk.workspace_bytes() / 1e9, "per_kernel_events_in_timed_region": not args.no_prof,
                        "event_readback_ms_after_timed_region": round(prof_read_ms, 3)},
         }
         out["config"]["mean_cg_iters_x_zu_zd"] = [round(cg_counts[k2], 2) for k2 in ("CG_iter_x", "CG_iter_zu", "CG_iter_zd")]
-        out["roofline"] = roofline_from_prof(prof, args.workload, path, blk=blk, B=B, cg=cg_counts) if prof else None
+        out["roofline"] = roofline_from_prof(prof, args.workload, path, blk=blk, B=Bc, cg=cg_counts) if prof else None
 
     # ---- CG-SpMV roofline leg on the 10k-node graph (BASELINE config 3), rank 0 of a 1-GPU run only
     if rank == 0 and world == 1 and args.workload == "cfg2" and not args.no_cfg3_leg:
