@@ -341,7 +341,8 @@ def main():
     # warm-up (untimed): creates the solver workspace and the HIP event pool, pages kernels in
     run(max(1, args.warmup), False)
     if not args.no_prof:
-        run(1, True)                        # the event pool of mgadmm_prof_begin is created on first use
+        run(args.steps, True)               # the event pool of mgadmm_prof_begin is created on first use; a solve of the timed
+                                            # length also allocates whatever depends on the iteration count
         blk.prof_end()
     barrier()
     t0 = time.perf_counter()
