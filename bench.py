@@ -233,7 +233,7 @@ def lds_bytes_per_launch(blk, B, cg, T=24):
     return B * per_sample, tpg
 
 
-def roofline_from_prof(prof, workload, path="stream", blk=None, B=0, cg=None):
+def roofline_from_prof(prof, workload, path="stream", blk=None, B=0, cg=None, steps=0):
     """Roofline object of the dominant kernel from the live HIP-event timings (tag 0); see the module docstring."""
     p0 = prof[0]
     if p0["count"] == 0 or p0["ms"] <= 0:
@@ -241,12 +241,17 @@ def roofline_from_prof(prof, workload, path="stream", blk=None, B=0, cg=None):
     avg_ms = p0["ms"] / p0["count"]
     traffic = load_traffic(workload)
     if path == "lds":
-        bytes_per, tpg = lds_bytes_per_launch(blk, B, cg)
+        bytes_it, tpg = lds_bytes_per_launch(blk, B, cg)
+        ipl = steps / p0["count"] if steps else 1.0       # ADMM iterations per launch (chunked schedule: a workgroup keeps its sample)
+        bytes_per = bytes_it * ipl
+        if traffic:
+            traffic = traffic * ipl                       # profiles/traffic.json holds HBM bytes per ITERATION of the batch
         ach = bytes_per / (avg_ms * 1e-3) / 1e9
-        out = {"bound": "lds", "kernel": f"k_admm_lds<TPG={tpg}> (LDS-resident fused ADMM iteration: 3 CG solves + prox + duals + "
-                                         "history per launch; one workgroup per sample)",
+        out = {"bound": "lds", "kernel": f"k_admm_lds<TPG={tpg}> (LDS-resident fused ADMM iterations: 3 CG solves + prox + duals + "
+                                         "history per iteration; one workgroup per sample, several iterations per launch)",
                "achieved": ach, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": ach / LDS_PEAK_GBS, "traffic": traffic,
-               "launches": p0["count"], "avg_launch_us": avg_ms * 1e3, "lds_bytes_per_launch": bytes_per,
+               "launches": p0["count"], "avg_launch_us": avg_ms * 1e3, "iterations_per_launch": ipl,
+               "avg_iteration_us": avg_ms * 1e3 / ipl, "lds_bytes_per_launch": bytes_per,
                "hbm_achieved": (traffic / (avg_ms * 1e-3) / 1e9) if traffic else None,
                "hbm_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                "note": "vectors live in LDS/registers inside the CG solves: priced against the LDS pipe; `traffic`/`hbm_*` = HBM bytes "
@@ -381,7 +386,7 @@ def main():
                        "event_readback_ms_after_timed_region": round(prof_read_ms, 3)},
         }
         out["config"]["mean_cg_iters_x_zu_zd"] = [round(cg_counts[k2], 2) for k2 in ("CG_iter_x", "CG_iter_zu", "CG_iter_zd")]
-        out["roofline"] = roofline_from_prof(prof, args.workload, path, blk=blk, B=Bc, cg=cg_counts) if prof else None
+        out["roofline"] = roofline_from_prof(prof, args.workload, path, blk=blk, B=Bc, cg=cg_counts, steps=args.steps * chunks) if prof else None
 
     # ---- CG-SpMV roofline leg on the 10k-node graph (BASELINE config 3), rank 0 of a 1-GPU run only
     if rank == 0 and world == 1 and args.workload == "cfg2" and not args.no_cfg3_leg:

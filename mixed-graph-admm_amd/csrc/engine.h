@@ -32,6 +32,7 @@ enum VecId {
 constexpr int LAG = 2;          // CG iterations enqueued ahead of the host's convergence check
 constexpr int NRED_MAX = 6;
 constexpr int PROF_POOL = 32768;
+constexpr int LDS_MAXJ_POOL = 7;     // longest chunk of the LDS path's chunked schedule: 2 (J - 1) + 3 iterate buffers out of the workspace
 constexpr int NACT_LOG = 1 << 16;   // pinned log of the per-iteration active-sample counts (one int per CG iteration enqueued)
 
 template <typename S>
@@ -82,8 +83,9 @@ struct Engine : EngineBase {
     // LDS-resident fused path (float32, small graphs)
     struct LdsPlan {
         bool ok = false;
-        int G = 0, TPG = 0, TS = 0, nthreads = 0, block = 0, csr_ints = 0, maxt = 1024, sb = 0, uniform45 = 0;
-        int off_rp_u = 0, off_rp_d = 0, off_rp_t = 0, off_en_u = 0, off_en_d = 0, off_en_t = 0;
+        int G = 0, TPG = 0, TS = 0, nthreads = 0, block = 0, NR = 0, csr_ints = 0, maxt = 1024, sb = 0, uniform45 = 0, slots = 0;
+        int tail_pairs = 0, lds_img0 = 0, lds_img_ints = 0;
+        int off_rp_u = 0, off_rp_d = 0, off_en_u = 0, off_en_d = 0, off_lead_t = 0, off_tail_t = 0;
         size_t lds_bytes = 0;
     } lds;
     int* d_lds_csr = nullptr;
@@ -92,7 +94,8 @@ struct Engine : EngineBase {
     // stream for the whole-batch metric kernels and the events that order the two streams
     int lds_async = 1;            // MGADMM_LDS_ASYNC=0: one stream, the host tests the stop criterion after every iteration
     int* d_stop = nullptr;
-    double* d_ps2 = nullptr;
+    double* d_ps_ring = nullptr;  // [2][J][NMETRIC][Bp]: per-sample metric sums of the chunked schedule (two chunks in flight)
+    int lds_chunk = 7;            // MGADMM_LDS_CHUNK: ADMM iterations per k_admm_lds launch when the iteration count is fixed (1 .. LDS_MAXJ_POOL)
     hipStream_t st_side = nullptr;
     hipEvent_t ev_main[3] = {nullptr}, ev_side[3] = {nullptr};
     // profiling
@@ -116,7 +119,7 @@ struct Engine : EngineBase {
         auto fr = [](void* q) { if (q) (void)hipFree(q); };
         fr(vec_pool); fr(partials); fr(d_rr); fr(d_alpha); fr(d_beta); fr(d_alpha_hist); fr(d_beta_hist);
         fr(d_active); fr(d_iters_tmp); fr(d_nact); fr(d_nonfinite); fr(d_ps); fr(d_hist); fr(d_dxps);
-        fr(d_dxpart); fr(d_hist_ps); fr(d_cg_iters); fr(d_lds_csr); fr(d_m2); fr(d_stop); fr(d_ps2);
+        fr(d_dxpart); fr(d_hist_ps); fr(d_cg_iters); fr(d_lds_csr); fr(d_m2); fr(d_stop); fr(d_ps_ring);
         if (st_side) (void)hipStreamDestroy(st_side);
         for (auto& e : ev_main) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_side) if (e) (void)hipEventDestroy(e);
@@ -420,6 +423,7 @@ struct Engine : EngineBase {
         if (const char* e = getenv("MGADMM_SWEEP_REV")) sweep_rev = atoi(e);
         if (const char* e = getenv("MGADMM_CLDR_ORDER")) cldr_tile_major = atoi(e);
         if (const char* e = getenv("MGADMM_LDS_ASYNC")) lds_async = atoi(e);
+        if (const char* e = getenv("MGADMM_LDS_CHUNK")) lds_chunk = std::max(1, std::min(atoi(e), LDS_MAXJ_POOL));
         Geom q = make_geom(Bmax);
         Bp_max = q.Bp;
         // Bp for smaller batches never exceeds Bp_max rounded to 256
@@ -1336,52 +1340,88 @@ struct Engine : EngineBase {
         }
         if (!best) return MGADMM_OK;
         const bool band = g->mode == MGADMM_TEMPORAL_BAND;
-        const int nu = g->hWu.nnz(), nd = band ? 0 : g->hWd.nnz(), nt = band ? 0 : g->hWdT.nnz();
-        int off = 0;
-        lds.off_rp_u = off; off += N + 1;
-        lds.off_rp_d = off; off += N + 1;
-        lds.off_rp_t = off; off += N + 1;
-        off += off & 1;
-        lds.off_en_u = off; off += 2 * nu;
-        lds.off_en_d = off; off += 2 * nd;
-        lds.off_en_t = off; off += 2 * nt;
-        off += 2 * (LDS_NLEAD + 3);    // padding entries: gather_lead reads LDS_NLEAD entries of the last row, the paired loop three ahead
-        lds.csr_ints = off;
-        // LDS row stride: T padded to an odd number of 16-byte slots (rows then start on every bank group);
-        // fall back to the unpadded stride when the padded vectors do not fit
-        int ts = (T + 3) / 4 * 4;
-        if (((ts / 4) & 1) == 0) ts += 4;
-        const int sb = getenv("MGADMM_LDS_SB") ? atoi(getenv("MGADMM_LDS_SB")) : 0;   // 1: one LDS vector for p and q (experiments)
-        auto bytes_for = [&](int stride) { return (size_t)(sb ? 4 : 8) * N * stride + 16 + 32 * sizeof(float) +  (size_t)4 * off; };   // P, Q + reduction slots + CSR image
-        if (bytes_for(ts) > 160 * 1024) ts = T;
-        lds.TS = ts;
-        lds.lds_bytes = bytes_for(ts);
-        if (lds.lds_bytes > 160 * 1024) return MGADMM_OK;
+        const int sb_env = getenv("MGADMM_LDS_SB") ? atoi(getenv("MGADMM_LDS_SB")) : 0;   // 1: one LDS vector for p and q (experiments)
         lds.TPG = best;
         lds.G = T / best;
         lds.nthreads = N * lds.G;
         lds.block = (lds.nthreads + 63) / 64 * 64;
-        lds.sb = sb ? 1 : 0;
-        // kNN tables with k = 4 and no pads (the reference's setting): every W_u row has 4, every W_d row 5 entries
-        lds.uniform45 = (!band && !getenv("MGADMM_LDS_RAGGED")) ? 1 : 0;
-        for (int i = 0; i < N && lds.uniform45; ++i)
-            if (g->hWu.rowptr[i + 1] - g->hWu.rowptr[i] != 4 || g->hWd.rowptr[i + 1] - g->hWd.rowptr[i] != 5) lds.uniform45 = 0;
         // register budget: the kernel is compiled for the smallest workgroup-size class that holds the block
         lds.maxt = (best == 12 && lds.block <= 640) ? 640 : 1024;
-        if (lds.sb && !((best == 12 && lds.maxt == 640) || best == 8)) lds.sb = 0;
+        lds.sb = (sb_env && ((best == 12 && lds.maxt == 640) || best == 8)) ? 1 : 0;
+        // the threads of the last wave that own no element are GHOSTS (lds_kernels.h): each gets an LDS row of zeros and table
+        // rows of zero weights
+        const int NR = N + (lds.block - lds.nthreads);
+        lds.NR = NR;
+        // kNN tables with k = 4 and no pads (the reference's setting): every W_u row has 4, every W_d row 5 entries -> the
+        // instance with unrolled gathers that reads its rows from the global image
+        lds.uniform45 = (!band && best == 8 && !lds.sb && lds.maxt == 1024 && !getenv("MGADMM_LDS_RAGGED")) ? 1 : 0;
+        for (int i = 0; i < N && lds.uniform45; ++i)
+            if (g->hWu.rowptr[i + 1] - g->hWu.rowptr[i] != 4 || g->hWd.rowptr[i + 1] - g->hWd.rowptr[i] != 5) lds.uniform45 = 0;
+        // W_d^T: LDS_NLEAD leading entries per row + a tail table of 2 * tail_pairs entries per row (rows padded with
+        // {own row, weight 0}): one trip count for every lane of the workgroup
+        int maxlen_t = 0;
+        if (!band)
+            for (int i = 0; i < N; ++i) maxlen_t = std::max(maxlen_t, g->hWdT.rowptr[i + 1] - g->hWdT.rowptr[i]);
+        const int tp = band ? 0 : (std::max(0, maxlen_t - LDS_NLEAD) + 1) / 2;
+        const int WT = LDS_NLEAD + 2 * tp;
+        lds.tail_pairs = tp;
+        // host tables with the ghosts' rows appended
+        auto with_ghosts = [&](const HostCsr& h, int fixed_len) {
+            HostCsr o;
+            o.rowptr.assign(h.rowptr.begin(), h.rowptr.begin() + N + 1);
+            o.col = h.col; o.val = h.val;
+            for (int r = N; r < NR; ++r) {
+                for (int e = 0; e < fixed_len; ++e) { o.col.push_back(r); o.val.push_back(0.f); }
+                o.rowptr.push_back((int)o.col.size());
+            }
+            return o;
+        };
+        const HostCsr hu = with_ghosts(g->hWu, lds.uniform45 ? 4 : 0);
+        const HostCsr hd = band ? HostCsr() : with_ghosts(g->hWd, lds.uniform45 ? 5 : 0);
+        const int nu = hu.nnz(), nd = band ? 0 : hd.nnz();
+        auto al4 = [](int v) { return (v + 3) & ~3; };
+        int off = 0;
+        lds.off_rp_u = off; off += NR + 1;
+        lds.off_rp_d = off; off += NR + 1;
+        off = al4(off);
+        lds.off_en_u = off; off += 2 * nu;
+        lds.off_en_d = off; off += 2 * nd;
+        lds.off_lead_t = off; off += 2 * NR * LDS_NLEAD;
+        off = al4(off);
+        lds.off_tail_t = off; off += 2 * NR * 2 * tp + 4;     // + one pair: gather_tail requests the next pair ahead
+        const int tail_ints = off - lds.off_tail_t;
+        off += 8;                                            // the paired loops of the ragged gathers read three entries ahead
+        lds.csr_ints = off;
+        lds.lds_img0 = lds.uniform45 ? lds.off_tail_t : 0;
+        lds.lds_img_ints = lds.uniform45 ? tail_ints : off;
+        // LDS row stride: T padded to an odd number of 16-byte slots (rows then start on every bank group);
+        // fall back to the unpadded stride when the padded vectors do not fit
+        int ts = (T + 3) / 4 * 4;
+        if (((ts / 4) & 1) == 0) ts += 4;
+        auto bytes_for = [&](int stride, int slots) {
+            const size_t LN = (size_t)NR * stride;
+            return sizeof(float) * ((lds.sb ? 1 : 2) * LN + ((4 - (LN & 3)) & 3) + 32 + 16 * 12 + (size_t)slots * 2 * lds.block * best)
+                   + sizeof(int) * (size_t)lds.lds_img_ints;
+        };
+        if (bytes_for(ts, 0) > 160 * 1024) ts = T;
+        lds.TS = ts;
+        if (bytes_for(ts, 0) > 160 * 1024) { lds = LdsPlan(); return MGADMM_OK; }
+        // two more LDS vectors for per-thread operands (uniform instance): when they fit beside the padded images
+        lds.slots = (lds.uniform45 && !getenv("MGADMM_LDS_NOSLOTS") && bytes_for(ts, 1) <= 160 * 1024) ? 1 : 0;
+        lds.lds_bytes = bytes_for(ts, lds.slots);
         std::vector<int> img(off, 0);
         // Bank-aware entry order (lds_banks.h).  A gather instruction reads entry e of 64 consecutive threads' rows (64
         // consecutive nodes, mostly); ds_read_b128 serves it in four groups of 16 lanes, and two lanes of a group collide
         // when their neighbour rows start in the same 16-byte slot of the 256-byte bank line.  WHICH neighbour sits in entry
         // e of a row is free.  Round 1 kept the table order (36 % of the LDS cycles of k_admm_lds were bank conflicts); round 2
-        // a greedy order, rows in node order (20 % -- and a timing build with conflict-free gathers showed that those 20 %
-        // cost 18 % of the launch); now the greedy order is the start of a min-conflicts search against an exact replay
-        // of the kernel's read stream (ldsbank::improve_targeted): cfg2 goes from 7 800 to 1 200 weighted conflict cycles
-        // in 0.15 s of host time per solver.  The sum of a row runs in the chosen order (fixed per graph: repeatable).
+        // a greedy order, rows in node order, as the start of a min-conflicts search against an exact replay of the kernel's
+        // read stream (ldsbank::improve_targeted): cfg2 goes from 7 800 to 1 200 weighted conflict cycles in 0.15 s of host
+        // time per solver.  The sum of a row runs in the chosen order (fixed per graph: repeatable).
         // MGADMM_LDS_TABLE_ORDER=1 keeps the table order, MGADMM_LDS_BANK_SEARCH=<steps> sets the search length (0: greedy only).
         const bool bank_order = !band && best % 4 == 0 && ((lds.TS / 4) & 1) && !getenv("MGADMM_LDS_TABLE_ORDER");
         long search_steps = 1500;
         if (const char* e = getenv("MGADMM_LDS_BANK_SEARCH")) search_steps = atol(e);
+        // order[e] = index into h.col / h.val of the entry the kernel reads at position e (real rows only; ghosts' rows follow as they are)
         auto slot_order = [&](const HostCsr& h, ldsbank::Stream stream) {
             std::vector<int> order(h.nnz());
             for (int e = 0; e < h.nnz(); ++e) order[e] = e;
@@ -1389,7 +1429,10 @@ struct Engine : EngineBase {
             ldsbank::Geometry q;
             q.N = N; q.G = T / best; q.TPG = best; q.TS = lds.TS; q.nlead = LDS_NLEAD;
             ldsbank::Mat m;
-            m.rowptr = h.rowptr; m.col = h.col; m.src = order; m.stream = stream;
+            m.rowptr.assign(h.rowptr.begin(), h.rowptr.begin() + N + 1);
+            m.col.assign(h.col.begin(), h.col.begin() + h.rowptr[N]);
+            m.src.assign(order.begin(), order.begin() + h.rowptr[N]);
+            m.stream = stream;
             ldsbank::greedy_order(q, m);
             if (search_steps > 0) {
                 std::vector<int> pos(N);
@@ -1397,30 +1440,55 @@ struct Engine : EngineBase {
                 const ldsbank::Result r = ldsbank::improve_targeted(q, m, pos, search_steps);
                 if (getenv("MGADMM_LDS_BANK_STATS"))
                     fprintf(stderr, "[mgadmm] lds bank search: stream %d, %d entries: %.0f -> %.0f conflict cycles per application (%ld steps)\n",
-                            (int)stream, h.nnz(), r.before, r.after, r.moves);
+                            (int)stream, h.rowptr[N], r.before, r.after, r.moves);
             }
-            return m.src;
+            for (int e = 0; e < h.rowptr[N]; ++e) order[e] = m.src[e];
+            return order;
+        };
+        auto put_entry = [&](int at, int col, float w) {
+            img[at] = col * lds.TS;                           // LDS float offset of the neighbour's time row
+            memcpy(&img[at + 1], &w, 4);
         };
         auto put_csr = [&](const HostCsr& h, int off_rp, int off_en, ldsbank::Stream stream) {
             const std::vector<int> order = slot_order(h, stream);
-            for (int i = 0; i <= N; ++i) img[off_rp + i] = h.rowptr[i];
-            for (int e = 0; e < h.nnz(); ++e) {
-                img[off_en + 2 * e] = h.col[order[e]] * lds.TS;       // LDS float offset of the neighbour's time row
-                memcpy(&img[off_en + 2 * e + 1], &h.val[order[e]], 4);
-            }
+            for (int i = 0; i <= NR; ++i) img[off_rp + i] = h.rowptr[i];
+            for (int e = 0; e < h.nnz(); ++e) put_entry(off_en + 2 * e, h.col[order[e]], h.val[order[e]]);
         };
-        const ldsbank::Stream fixed_or_pairs = lds.uniform45 ? ldsbank::FIXED : ldsbank::PAIRS;     // gather_fixed / gather
-        put_csr(g->hWu, lds.off_rp_u, lds.off_en_u, fixed_or_pairs);
+        const ldsbank::Stream fixed_or_pairs = lds.uniform45 ? ldsbank::FIXED : ldsbank::PAIRS;     // gather_regs / gather
+        put_csr(hu, lds.off_rp_u, lds.off_en_u, fixed_or_pairs);
         if (!band) {
-            put_csr(g->hWd, lds.off_rp_d, lds.off_en_d, fixed_or_pairs);
-            put_csr(g->hWdT, lds.off_rp_t, lds.off_en_t, ldsbank::LEAD_PAIRS);      // gather_lead
+            put_csr(hd, lds.off_rp_d, lds.off_en_d, fixed_or_pairs);
+            // W_d^T as a table of WT entries per row: the row's entries, then {own row, 0}; every lane reads every position
+            // (FIXED stream of the bank model), the first LDS_NLEAD positions from registers, the others from the tail table
+            HostCsr ht;
+            ht.rowptr.push_back(0);
+            std::vector<int> from;                            // index into hWdT, -1: padding
+            for (int i = 0; i < N; ++i) {
+                const int e0 = g->hWdT.rowptr[i], len = g->hWdT.rowptr[i + 1] - e0;
+                for (int e = 0; e < WT; ++e) {
+                    ht.col.push_back(e < len ? g->hWdT.col[e0 + e] : i);
+                    ht.val.push_back(e < len ? g->hWdT.val[e0 + e] : 0.f);
+                    from.push_back(e < len ? e0 + e : -1);
+                }
+                ht.rowptr.push_back((int)ht.col.size());
+            }
+            const std::vector<int> order = slot_order(ht, ldsbank::FIXED);
+            for (int r = 0; r < NR; ++r)
+                for (int e = 0; e < WT; ++e) {
+                    const int at = e < LDS_NLEAD ? lds.off_lead_t + 2 * (r * LDS_NLEAD + e)
+                                                 : lds.off_tail_t + 2 * (r * 2 * tp + (e - LDS_NLEAD));
+                    if (r < N) put_entry(at, ht.col[order[r * WT + e]], ht.val[order[r * WT + e]]);
+                    else put_entry(at, r, 0.f);
+                }
+            put_entry(lds.off_tail_t + 2 * NR * 2 * tp, 0, 0.f);
+            put_entry(lds.off_tail_t + 2 * NR * 2 * tp + 2, 0, 0.f);
         }
         MG_HIP(hipMalloc(&d_lds_csr, sizeof(int) * off));
         MG_HIP(hipMemcpy(d_lds_csr, img.data(), sizeof(int) * off, hipMemcpyHostToDevice));
         MG_HIP(hipMalloc(&d_m2, sizeof(double) * T * N * (1 + (size_t)(Bmax + 63) / 64)));
         MG_HIP(hipMalloc(&d_stop, sizeof(int)));
         MG_HIP(hipMemset(d_stop, 0, sizeof(int)));
-        MG_HIP(hipMalloc(&d_ps2, sizeof(double) * MGADMM_NMETRIC * Bp_max));
+        MG_HIP(hipMalloc(&d_ps_ring, sizeof(double) * 2 * LDS_MAXJ_POOL * MGADMM_NMETRIC * Bp_max));
         {
             // helper stream of the overlapped outer loop: non-blocking (the caller's stream may be the legacy default stream,
             // which would serialise a blocking stream with itself), lowest priority (the k_admm_lds workgroups of the next
@@ -1438,7 +1506,7 @@ struct Engine : EngineBase {
 
     int launch_lds(const LdsArgs& a, int B) {
         const bool timed = prof_open(0, 0.0);
-        LdsLaunch L{lds.TPG, lds.maxt, lds.sb, lds.uniform45, lds.block, lds.lds_bytes};
+        LdsLaunch L{lds.TPG, lds.maxt, lds.sb, lds.uniform45, lds.slots, lds.block, lds.lds_bytes};
         const int rc = mg_lds_iteration(L, a, B, st);
         if (timed) prof_close();
         return rc;
@@ -1474,26 +1542,33 @@ struct Engine : EngineBase {
             //   DEVSTOP  (check_stop) one stream, the stop test runs on the device (k_lds_stop_test sets the stop word, every
             //            later launch returns at its guard), the host enqueues iterations ahead and looks at the word LAG
             //            iterations late: same iterates and history, no host round trip per iteration;
-            //   OVERLAP  (fixed iteration count) the whole-batch metric kernels of iteration k (delta_x_per_step re-reads x and
-            //            x_old of the batch, 241 MB at cfg2) run on a helper stream beside the k_admm_lds launch of iteration
-            //            k+1, which leaves HBM idle; x rotates through three buffers and the per-sample metric sums through
-            //            two, so that launch k+1 overwrites nothing the metric kernels of iteration k still read; launch k+2
-            //            waits for them.
-            enum { SYNC, DEVSTOP, OVERLAP };
-            const int sched = (!lds_async || record) ? SYNC : (p.check_stop ? DEVSTOP : OVERLAP);
+            //   CHUNKS   (fixed iteration count) one k_admm_lds launch runs a CHUNK of J iterations on every sample (the workgroup
+            //            keeps its sample: see the kernel); every iterate x_k goes to a buffer of its own, and the whole-batch
+            //            metric kernels of a chunk (delta_x_per_step re-reads x_k and x_{k+1} of the batch, 241 MB per iteration
+            //            at cfg2) run on a helper stream beside the launch of the next chunk, which leaves HBM idle.  Iterates
+            //            at chunk boundaries rotate through three buffers, the iterates inside a chunk and the per-sample metric
+            //            sums through two sets: launch c+2 overwrites what the metric kernels of chunk c read and waits for them.
+            //            J = 1 is the overlapped one-iteration-per-launch schedule of round 2.
+            enum { SYNC, DEVSTOP, CHUNKS };
+            const int sched = (!lds_async || record) ? SYNC : (p.check_stop ? DEVSTOP : CHUNKS);
             // The caller's output buffers ARE the working state of this path (same (B, T*N) layout): no copy-out at the end
-            // (round 2 until here: seven 120 MB device copies per solve at cfg2 = 0.7 ms of a 59 ms solve).  x rotates
-            // through two (three: OVERLAP) buffers; they are assigned so that the iterate of the LAST iteration lands in
-            // x_out (an early stop on another buffer costs one copy).  Outputs must not alias y / mask (mgadmm.h).
+            // (round 2 until here: seven 120 MB device copies per solve at cfg2 = 0.7 ms of a 59 ms solve).  The iterates are
+            // assigned to buffers so that the one of the LAST iteration lands in x_out (an early stop on another buffer
+            // costs one copy).  Outputs must not alias y / mask (mgadmm.h).
             auto pick = [&](void* out, float* own) { return out ? static_cast<float*>(out) : own; };
             float* const xo_ = static_cast<float*>(x_out);
-            const int NX = sched == OVERLAP ? 3 : 2;
-            float* X[3] = {nullptr, nullptr, nullptr};      // iteration `it` reads X[it % NX] and writes X[(it + 1) % NX]
-            {
-                float* own[2] = {vec[V_XA], vec[V_XB]};
-                int o = 0;
-                for (int j = 0; j < NX; ++j) X[j] = (j == max_it % NX) ? xo_ : own[o++];
-            }
+            // buffers for the iterates: the workspace vectors this path does not use otherwise
+            static const int ring_ids[] = {V_XA, V_XB, V_ZUB, V_ZDB, V_PHIB, V_Y, V_MASK, V_R, V_P, V_Q, V_AP, V_RHS, V_TMP, V_IO0, V_IO1};
+            constexpr int NRING = (int)(sizeof(ring_ids) / sizeof(ring_ids[0]));
+            static_assert(NRING >= 2 * (LDS_MAXJ_POOL - 1) + 3, "iterate buffers of the chunked schedule");
+            const int J = sched == CHUNKS ? std::max(1, std::min(std::min(lds_chunk, LDS_MAXJ_POOL), max_it)) : 1;
+            // iterate k (k = 0: the initial guess) lives in xbuf(k)
+            auto xbuf = [&](int k) -> float* {
+                if (k == max_it) return xo_;
+                if (sched != CHUNKS) return vec[ring_ids[k & 1]];
+                if (k % J == 0) return vec[ring_ids[(k / J) % 3]];                          // chunk boundary
+                return vec[ring_ids[3 + ((k / J) & 1) * (J - 1) + (k % J - 1)]];           // inside chunk k / J
+            };
             float *zu = pick(state_out ? state_out->zu : nullptr, vec[V_ZUA]), *zd = pick(state_out ? state_out->zd : nullptr, vec[V_ZDA]);
             float *phi = pick(state_out && has_phi ? state_out->phi : nullptr, vec[V_PHIA]), *gam = pick(state_out && has_phi ? state_out->gamma : nullptr, vec[V_GAM]);
             float *gu = pick(state_out ? state_out->gamma_u : nullptr, vec[V_GU]), *gd = pick(state_out ? state_out->gamma_d : nullptr, vec[V_GD]);
@@ -1502,7 +1577,7 @@ struct Engine : EngineBase {
                 auto cp = [&](float* dst, const void* src) {
                     return (src == nullptr || dst == src) ? hipSuccess : hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, st);
                 };
-                MG_HIP(cp(X[0], x0));
+                MG_HIP(cp(xbuf(0), x0));
                 MG_HIP(cp(zu, state_in->zu));
                 MG_HIP(cp(gu, state_in->gamma_u));
                 MG_HIP(cp(zd, state_in->zd));            // the vectors an ablation does not iterate on are carried through
@@ -1515,12 +1590,12 @@ struct Engine : EngineBase {
                 tm /= (float)p.t_in;
                 t2m /= (float)p.t_in;
                 const float den = t2m - tm * tm;
-                MG_TRY(mg_lds_init(mask != nullptr, T, p.t_in, N, B, tm, den, (const float*)y, (const float*)mask, X[0], zu, zd, gam, gu, gd,
+                MG_TRY(mg_lds_init(mask != nullptr, T, p.t_in, N, B, tm, den, (const float*)y, (const float*)mask, xbuf(0), zu, zd, gam, gu, gd,
                                    d_nonfinite, st));
             }
             LdsArgs a{};
             a.T = T; a.N = N; a.TN = (int)TN; a.TS = lds.TS; a.t_in = p.t_in; a.G = lds.G; a.B = B; a.Bp = Bp;
-            a.nthreads = lds.nthreads;
+            a.nthreads = lds.nthreads; a.NR = lds.NR; a.tail_pairs = lds.tail_pairs;
             a.has_phi = has_phi; a.has_zd = has_zd;
             const LhsDef dx = lhs_def(MGADMM_LHS_X);
             a.lhsx_kind = dx.kind == 1 ? 1 : 0;
@@ -1530,10 +1605,10 @@ struct Engine : EngineBase {
             a.max_cg = p.max_cg_iter; a.record = record ? 1 : 0;
             a.rho = (float)p.rho; a.rho_u = (float)p.rho_u; a.rho_d = (float)p.rho_d;
             a.mu_u = (float)p.mu_u; a.mu_d1 = (float)p.mu_d1; a.mu_d2 = (float)p.mu_d2;
-            a.cg_tol = p.cg_tol;
-            a.csr = d_lds_csr; a.csr_ints = lds.csr_ints;
-            a.off_rp_u = lds.off_rp_u; a.off_rp_d = lds.off_rp_d; a.off_rp_t = lds.off_rp_t;
-            a.off_en_u = lds.off_en_u; a.off_en_d = lds.off_en_d; a.off_en_t = lds.off_en_t;
+            a.cg_tol2 = p.cg_tol * p.cg_tol;
+            a.csr = d_lds_csr; a.lds_img0 = lds.lds_img0; a.lds_img_ints = lds.lds_img_ints;
+            a.off_rp_u = lds.off_rp_u; a.off_rp_d = lds.off_rp_d;
+            a.off_en_u = lds.off_en_u; a.off_en_d = lds.off_en_d; a.off_lead_t = lds.off_lead_t; a.off_tail_t = lds.off_tail_t;
             a.band_w = g->band_w;
             a.zu = zu; a.zd = zd; a.phi = phi; a.gam = gam; a.gu = gu; a.gd = gd;
             // staggered start (k_admm_lds): only when the launch runs several rounds of workgroups per CU
@@ -1549,38 +1624,48 @@ struct Engine : EngineBase {
             a.nonfinite = d_nonfinite;
             a.stop = sched == DEVSTOP ? d_stop : nullptr;
             if (sched == DEVSTOP) MG_HIP(hipMemsetAsync(d_stop, 0, sizeof(int), st));
-            if (sched == OVERLAP) MG_HIP(hipMemsetAsync(d_ps2, 0, sizeof(double) * MGADMM_NMETRIC * Bp, st));
+            if (sched == CHUNKS) MG_HIP(hipMemsetAsync(d_ps_ring, 0, sizeof(double) * 2 * J * MGADMM_NMETRIC * Bp, st));
             const size_t K = p.max_cg_iter;
             int n_done = 0, rc_final = MGADMM_OK;
-            double* const ps_buf[2] = {d_ps, d_ps2};
             // the whole-batch metrics of iteration `it` (delta_x_per_step, norms / means over the samples) on stream `s`
             auto batch_metrics = [&](int it, const double* ps, hipStream_t s) -> int {
-                MG_TRY(mg_lds_dxps(T, N, B, (const float*)X[(it + 1) % NX], (const float*)X[it % NX], d_m2, d_dxps + (size_t)it * T, a.stop, s));
+                MG_TRY(mg_lds_dxps(T, N, B, (const float*)xbuf(it + 1), (const float*)xbuf(it), d_m2, d_dxps + (size_t)it * T, a.stop, s));
                 hipLaunchKernelGGL(k_batch_metrics, dim3(MGADMM_NMETRIC), dim3(256), 0, s, ps, Bp, B,
                                    d_hist + (size_t)it * MGADMM_NMETRIC,
                                    (hist && hist->metrics_per_sample) ? d_hist_ps + (size_t)it * MGADMM_NMETRIC * B : nullptr);
                 MG_HIP(hipGetLastError());
                 return MGADMM_OK;
             };
-            for (int it = 0; it < max_it; ++it) {
+            if (sched == CHUNKS) {
+                int c = 0;
+                for (int it0 = 0; it0 < max_it; it0 += J, ++c) {
+                    const int Jc = std::min(J, max_it - it0);
+                    a.first = it0 == 0 && !state_in;      // phi = Ldr x0 is formed by the first iteration of a cold start
+                    a.J = Jc;
+                    for (int k = 0; k <= Jc; ++k) a.xs[k] = xbuf(it0 + k);
+                    a.cg_iters = d_cg_iters + (size_t)it0 * 3 * Bp;
+                    a.ps = d_ps_ring + (size_t)(c & 1) * J * MGADMM_NMETRIC * Bp;
+                    // launch c overwrites the iterate buffers and the metric sums that the metric kernels of chunk c-2 read
+                    if (c >= 2) MG_HIP(hipStreamWaitEvent(st, ev_side[(c - 2) % 3], 0));
+                    MG_TRY(launch_lds(a, B));
+                    MG_HIP(hipEventRecord(ev_main[c % 3], st));
+                    MG_HIP(hipStreamWaitEvent(st_side, ev_main[c % 3], 0));
+                    for (int k = 0; k < Jc; ++k) MG_TRY(batch_metrics(it0 + k, a.ps + (size_t)k * MGADMM_NMETRIC * Bp, st_side));
+                    MG_HIP(hipEventRecord(ev_side[c % 3], st_side));
+                    n_done = it0 + Jc;
+                }
+                if (c > 0)            // join the helper stream (its kernels run in order: the last event covers all)
+                    MG_HIP(hipStreamWaitEvent(st, ev_side[(c - 1) % 3], 0));
+            }
+            for (int it = 0; sched != CHUNKS && it < max_it; ++it) {
                 a.first = it == 0 && !state_in;      // phi = Ldr x0 is formed by the first launch of a cold start
-                a.x_old = X[it % NX]; a.x_new = X[(it + 1) % NX];
+                a.J = 1;
+                a.xs[0] = xbuf(it); a.xs[1] = xbuf(it + 1);
                 a.cg_iters = d_cg_iters + (size_t)it * 3 * Bp;
-                a.ps = sched == OVERLAP ? ps_buf[it & 1] : d_ps;
+                a.ps = d_ps;
                 if (record) {
                     MG_TRY(fill((S*)d_alpha_hist, 3 * K * Bp, (S)NAN));
                     MG_TRY(fill((S*)d_beta_hist, 3 * K * Bp, (S)NAN));
-                }
-                if (sched == OVERLAP) {
-                    // launch `it` overwrites the x buffer and the metric sums that the metric kernels of iteration it-2 read
-                    if (it >= 2) MG_HIP(hipStreamWaitEvent(st, ev_side[(it - 2) % 3], 0));
-                    MG_TRY(launch_lds(a, B));
-                    MG_HIP(hipEventRecord(ev_main[it % 3], st));
-                    MG_HIP(hipStreamWaitEvent(st_side, ev_main[it % 3], 0));
-                    MG_TRY(batch_metrics(it, a.ps, st_side));
-                    MG_HIP(hipEventRecord(ev_side[it % 3], st_side));
-                    n_done = it + 1;
-                    continue;
                 }
                 MG_TRY(launch_lds(a, B));
                 MG_TRY(batch_metrics(it, a.ps, st));
@@ -1616,8 +1701,6 @@ struct Engine : EngineBase {
                     if (pri < p.admm_tol && dual < p.admm_tol) break;
                 }
             }
-            if (sched == OVERLAP && n_done > 0)        // join the helper stream (its kernels run in order: the last event covers all)
-                MG_HIP(hipStreamWaitEvent(st, ev_side[(n_done - 1) % 3], 0));
             if (sched == DEVSTOP) {
                 // the stop word after everything enqueued has run: 0 = no stop (all enqueued iterations ran), k > 0 = the stop
                 // test passed at the end of iteration k - 1, k < 0 = iteration -k - 1 met a NaN / Inf
@@ -1627,7 +1710,7 @@ struct Engine : EngineBase {
                 if (sw > 0) n_done = sw;
                 else if (sw < 0) { n_done = -sw; rc_final = MGADMM_ERR_NONFINITE; }
             }
-            float* const xc = X[n_done % NX];
+            float* const xc = xbuf(n_done);
             if (xc != xo_)        // early stop on the other parity
                 MG_HIP(hipMemcpyAsync(x_out, xc, (size_t)B * TN * sizeof(float), hipMemcpyDeviceToDevice, st));
             return finish_history(hist, n_done, B, Bp, rc_final);

@@ -1,20 +1,20 @@
-// LDS-resident fused ADMM iteration for small graphs (PEMS-size: T*N*8 B + CSR fits the 160 KiB LDS).
+// LDS-resident fused ADMM iterations for small graphs (PEMS-size: T*N*8 B + tables fit the 160 KiB LDS).
 //
-// One workgroup = one sample.  One launch = one full ADMM iteration of reference ADMM.py:546-646:
-// RHS_x, the three CG solves (x, zu, zd) with all their iterations, the dual updates, the phi prox and
-// every residual / regulariser of the history.  Inside a CG solve nothing touches HBM:
+// One workgroup = one sample.  One launch = J full ADMM iterations of reference ADMM.py:546-646 on every sample (the
+// workgroup keeps its sample for the J trips): RHS_x, the three CG solves (x, zu, zd) with all their iterations, the dual
+// updates, the phi prox and every residual / regulariser of the history.  Inside a CG solve nothing touches HBM:
 //   * thread (g, i) owns node i at TPG consecutive time steps t0 = g*TPG ...; x, r, p, Ap of those
 //     elements live in registers for the whole solve;
-//   * a copy of the CG direction p (and of q = Ldr p) lives in LDS so that neighbours can be gathered, stored SHIFTED by
-//     the time offset of the operator that reads it (LdsCtx::put), so that every gather is an aligned ds_read_b128 run --
-//     the only LDS traffic of an iteration is those gathers and one store of p and q;
-//   * the three CSR matrices (W_u, W_d, W_d^T as packed {col, weight} pairs) live in LDS too; a thread
-//     reads each entry of ITS node's row once per operator application and applies it to its TPG time steps;
+//   * a copy of the CG direction p (and of q = Ldr p) lives in LDS so that neighbours can be gathered; every gather is an
+//     aligned ds_read_b128 run (lds_apply: shifted ownership of q) -- the only LDS traffic of an iteration is those
+//     gathers and one store of p and q;
+//   * a thread's rows of W_u, W_d and the leading entries of its W_d^T row ({LDS row offset, weight} pairs) sit in registers
+//     during a solve, the rest of the W_d^T rows in an LDS table padded to a uniform width;
+//   * idle threads of the last wave are GHOSTS that own rows of zeros: one instruction stream for everybody (LdsCtx);
 //   * p.Ap and r.r are reduced with wave shuffles + a 16-entry LDS exchange in fixed order (repeatable);
 //     alpha, beta and the convergence test are computed redundantly by every thread (workgroup-uniform).
 // State (x, zu, zd, phi, gamma*) is kept in HBM in the reference's own sample-major (B, T*N) layout, so the
-// ABI tensors need no layout conversion on this path; per ADMM iteration a sample moves ~35 vectors of
-// T*N*4 B through HBM instead of ~650.
+// ABI tensors need no layout conversion on this path.
 #pragma once
 #include "common.h"
 #include "lds_args.h"
@@ -63,9 +63,6 @@ struct BlockRed {
     // (all four rows compute the same sum in the same order); lane 15's value is broadcast.  8 VALU + 1 ds_read
     // instead of 15 VALU + 4 ds_read_b128 + two float<->double conversions per reduction.
     __device__ __forceinline__ float sumf(float v) {
-#ifdef MGADMM_KO_NORED           // knock-out timing build: no workgroup reduction (and none of its barriers)
-        return v + 1.0f;
-#endif
         v = wave_sum(v);
         float* buf = red + par * 16;
         if (lane == 0) buf[wave] = v;      // (all 64 lanes storing the same word instead: +1.2 % per launch)
@@ -129,180 +126,216 @@ __device__ __forceinline__ void lds_store(float* p, const float (&v)[TPG]) {
 __device__ __forceinline__ float ldg(const float* base, unsigned boff) {
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
 }
-// knock-out timing build MGADMM_KO_OWNROW: every gather reads the thread's OWN row instead of the neighbour's (consecutive
-// nodes -> distinct 16-byte slots: no bank conflict) -- same instruction stream, wrong results, tells what the conflicts cost
-// MGADMM_KO_CIRC: entry number u of every row reads node (i + u) mod N -- distinct rows per entry, consecutive nodes per
-// lane group: conflict-free under the bank model of lds_banks.h without the identical addresses of KO_OWNROW
-#if defined(MGADMM_KO_OWNROW)
-#define MG_ENX(x, u) (i * TS)
-#elif defined(MGADMM_KO_CIRC)
-#define MG_ENX(x, u) (((i + (u)) % N) * TS)
-#else
-#define MG_ENX(x, u) (x)
-#endif
+__device__ __forceinline__ void stg(float* base, unsigned boff, float v) {
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v;
+}
 // REQUEST fence: the loads before it are issued together and waited for together, nothing crosses it.
 #define MG_REQ_FENCE() asm volatile("" ::: "memory")
+// a workgroup-uniform value the optimiser must keep in a scalar register from here on (it would otherwise re-read a launch
+// argument from the kernarg segment inside a CG loop: a scalar load shares its counter with the LDS gathers in flight)
+#define MG_PIN_S(x) asm volatile("" : "+s"(x))
+#define MG_PIN_V(x) asm volatile("" : "+v"(x))      // ... a value that was computed (no scalar float unit): stays in a vector register
 
-// Per-thread view: node i, time steps t0 .. t0+TPG-1.
-//   LDS vectors are node-major, time innermost: A[node*TS + t] (row stride TS >= T, an odd number of 16-B
-//   slots so that rows start on all banks) -> the TPG time steps of any node are one contiguous, aligned
-//   run (vector ds_read), also for a gathered neighbour;
-//   HBM state is the reference's (T, N) order per sample: element (t, i) at t*N + i (coalesced over i).
+typedef int lds_i4 __attribute__((ext_vector_type(4)));
+// PACKED ARITHMETIC BY HAND.  This translation unit is compiled with -fno-slp-vectorize and the element loops of the CG
+// solves are written on pairs of floats (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on the register pairs (2j, 2j+1) of a
+// thread's vector): the SLP vectoriser pairs whatever looks profitable locally -- in the first branch-free build of round 3
+// it packed the shifted self terms of lds_apply (q[k] = v[k+1] - acc[k]) along v's pairs, which put every gathered 16-byte
+// piece one element off its accumulator pair (six register moves per table entry, 75 v_mov per CG iteration), and, once
+// that was blocked, packed ACROSS the table entries instead (moves, multiplies and adds in place of fused multiply-adds).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+// y[k] += a * x[k]
+template <int TPG>
+__device__ __forceinline__ void axpy(float a, const float (&x)[TPG], float (&y)[TPG]) {
+    if constexpr (TPG % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < TPG / 2; ++j) {
+            const f2 r = __builtin_elementwise_fma(mk2(a, a), mk2(x[2 * j], x[2 * j + 1]), mk2(y[2 * j], y[2 * j + 1]));
+            y[2 * j] = r.x; y[2 * j + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) y[k] = __builtin_fmaf(a, x[k], y[k]);
+    }
+}
+// y[k] = x[k] + b * y[k]
+template <int TPG>
+__device__ __forceinline__ void xpby(const float (&x)[TPG], float b, float (&y)[TPG]) {
+    if constexpr (TPG % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < TPG / 2; ++j) {
+            const f2 r = __builtin_elementwise_fma(mk2(b, b), mk2(y[2 * j], y[2 * j + 1]), mk2(x[2 * j], x[2 * j + 1]));
+            y[2 * j] = r.x; y[2 * j + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) y[k] = __builtin_fmaf(b, y[k], x[k]);
+    }
+}
+// sum_k x[k] * y[k]: two running sums over the even / odd elements, then their sum (fixed order)
+template <int TPG>
+__device__ __forceinline__ float dot(const float (&x)[TPG], const float (&y)[TPG]) {
+    if constexpr (TPG % 2 == 0) {
+        f2 acc = mk2(x[0], x[1]) * mk2(y[0], y[1]);
+#pragma unroll
+        for (int j = 1; j < TPG / 2; ++j) acc = __builtin_elementwise_fma(mk2(x[2 * j], x[2 * j + 1]), mk2(y[2 * j], y[2 * j + 1]), acc);
+        return acc.x + acc.y;
+    } else {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) acc = __builtin_fmaf(x[k], y[k], acc);
+        return acc;
+    }
+}
+// acc[k] += w * va[k]
+template <int TPG>
+__device__ __forceinline__ void wacc(float w, const float (&va)[TPG], float (&acc)[TPG]) { axpy<TPG>(w, va, acc); }
+
+// the two halves of RHS_x that do not need a neighbour, and the operand of its Ldr^T term (ADMM.py:556-564): ONE expression
+// each, used wherever the value is formed (from the state in HBM at the first trip of a launch, from the registers of the
+// previous trip afterwards), so that the result does not depend on how the iterations are cut into launches
+__device__ __forceinline__ float rhs_half(float rho, float z, float g) { return __builtin_fmaf(rho, z, -g) * 0.5f; }
+__device__ __forceinline__ float ldrt_operand(float rho, float phi, float gam) { return __builtin_fmaf(rho, phi, gam); }
+
+// Per-thread view: LDS row `i`, time steps t0 .. t0+TPG-1.
+//   Threads tid < N*G own node i = tid mod N at time group tid / N.  The other threads of the workgroup are GHOSTS: ghost k
+//   owns LDS row N + k (all zeros, written only by itself, with zeros) at time group 0, its table rows hold zero weights and
+//   point at its own row, its HBM accesses are clamped to node 0 and masked.  Ghosts run the same instruction stream as
+//   everybody else -- no `if (active)` regions, no per-lane trip counts inside the solves -- and add exact zeros to every
+//   sum.  (Until round 3 idle threads were masked off: an exec-mask region and a set of zeroing moves around every operator
+//   application; worse, the divergent tail loop of the ragged W_d^T gather made this kernel fragile under register pressure:
+//   hipcc 7.2 gave the exec-mask accumulator of that loop the SGPR pair that held the LDS address of the W_d^T table --
+//   profiles/r03/miscompile_s63_evidence.txt.)
+//   LDS vectors are row-major, time innermost: A[row*TS + t] (row stride TS >= T, an odd number of 16-B slots so that rows
+//   start on all banks) -> the TPG time steps of any node are one contiguous, aligned run (vector ds_read), also for a
+//   gathered neighbour; HBM state is the reference's (T, N) order per sample: element (t, i) at t*N + i (coalesced over i).
 template <int TPG, bool BAND, int NU = 0, int ND = 0>
 struct LdsCtx {
-    int T, TS, N, t0, i;
+    int T, TS, N, t0, i, ig;   // i: LDS row, ig: node in HBM (ghosts: 0)
     bool active;
     float* P;
     float* Q;
-    const int2* en_u; const int2* en_d; const int2* en_t;
-    int u0, u1, d0, d1, t0e, t1e;   // this node's CSR row bounds
+    const int2* en_u; const int2* en_d;      // entries of W_u / W_d rows (LDS image, or the global image: uniform instances)
+    const int2* lead_t;                      // W_d^T: [NR][LDS_NLEAD] leading entries (LDS or global image)
+    const int2* tail_t;                      // W_d^T: [NR][2 * tail_pairs] further entries (LDS), rows padded with {own row, 0}
+    int u0, u1, d0, d1;                      // CSR row bounds (ragged gathers)
+    int tail_pairs;
     int skip, q1;
     const float* band_w;
 
-    __device__ __forceinline__ int gl(int k) const { return (t0 + k) * N + i; }   // HBM index
-    __device__ __forceinline__ unsigned glb(int k) const { return 4u * (unsigned)((t0 + k) * N + i); }   // ... as a byte offset
+    __device__ __forceinline__ unsigned glb(int k) const { return 4u * (unsigned)((t0 + k) * N + ig); }   // HBM byte offset
     __device__ __forceinline__ int own() const { return i * TS + t0; }            // LDS index of element k = 0
 
-    // SHIFTED LDS IMAGES.  A vector that is only gathered through a time-shifted operator is stored shifted: the image
-    // read by Ldr (gathers x[t-1]) holds time t-1 at index t, the image read by Ldr^T (gathers x[t+1]) holds time t+1 at
-    // index t, 0 outside [0,T).  Every gather of a neighbour's TPG-step window is then the ALIGNED run [t0, t0+TPG-1]:
-    // conflict-free ds_read_b128 only, no edge group, no rotation of the accumulators (round 1 read an aligned run plus
-    // one more 16-byte group holding the edge element: 3 reads per entry at TPG = 8 instead of 2).  The price is the
-    // store of the own elements, unaligned by one float (scalar ds_write_b32; stores are 1/15 of the LDS traffic).
-    //
-    // acc[k] = sum_e w_e * IMG[col_e][t0+k].  Entries carry the LDS float offset of the neighbour's row (col*TS,
-    // precomputed on the host).  Two entries are in flight per trip (their LDS reads are issued together, the next pair
-    // of entries is fetched meanwhile); the sum runs in entry order.
-    __device__ __forceinline__ void gather(const float* SRC, const int2* EN, int e0, int e1, float (&acc)[TPG]) const {
+    // acc[k] += sum_e w_e * IMG[col_e + t0 + k] over NE entries held in registers.  Entries carry the LDS float offset of the
+    // neighbour's row (col * TS, formed on the host); every gather of a neighbour's TPG-step window is the ALIGNED run
+    // [t0, t0+TPG-1]: conflict-free ds_read_b128 only.  The sum runs in entry order.
+    template <int NE>
+    __device__ __forceinline__ void gather_regs(const float* SRC, const int2 (&en)[NE], float (&acc)[TPG]) const {
+        const float* base = SRC + t0;
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
-#ifdef MGADMM_KO_NOGATHER        // knock-out timing build (make EXTRA=-DMGADMM_KO_...): everything but the LDS gathers
-        return;
-#endif
+        for (int u = 0; u + 1 < NE; u += 2) {
+            float va[TPG], vb[TPG];
+            lds_load<TPG>(base + en[u].x, va);
+            lds_load<TPG>(base + en[u + 1].x, vb);
+            const float wa = __int_as_float(en[u].y), wb = __int_as_float(en[u + 1].y);
+            wacc<TPG>(wa, va, acc);
+            wacc<TPG>(wb, vb, acc);
+        }
+        if (NE & 1) {
+            float va[TPG];
+            lds_load<TPG>(base + en[NE - 1].x, va);
+            const float wa = __int_as_float(en[NE - 1].y);
+            wacc<TPG>(wa, va, acc);
+        }
+    }
+    // ragged rows of the generic instances (W_u / W_d with pads): two entries in flight per trip, per-lane trip count
+    __device__ __forceinline__ void gather(const float* SRC, const int2* EN, int e0, int e1, float (&acc)[TPG]) const {
         const float* base = SRC + t0;
         int2 na = EN[e0], nb = EN[e0 + 1];          // the arrays are padded by 3 entries: reads past e1 are safe
         int e = e0;
         for (; e + 1 < e1; e += 2) {
             const int2 ea = na, eb = nb;
             float va[TPG], vb[TPG];
-            lds_load<TPG>(base + MG_ENX(ea.x, e - e0), va);
-            lds_load<TPG>(base + MG_ENX(eb.x, e - e0 + 1), vb);
+            lds_load<TPG>(base + ea.x, va);
+            lds_load<TPG>(base + eb.x, vb);
             na = EN[e + 2];
             nb = EN[e + 3];
             const float wa = __int_as_float(ea.y), wb = __int_as_float(eb.y);
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) acc[k] += wb * vb[k];
+            wacc<TPG>(wa, va, acc);
+            wacc<TPG>(wb, vb, acc);
         }
         if (e < e1) {
             float va[TPG];
-            lds_load<TPG>(base + MG_ENX(na.x, e - e0), va);
+            lds_load<TPG>(base + na.x, va);
             const float wa = __int_as_float(na.y);
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
+            wacc<TPG>(wa, va, acc);
         }
     }
-    // The same for a matrix whose rows all hold exactly NFIX entries (W_u: k, W_d: k + 1 of a kNN table without pads):
-    // straight-line code, every entry of the row is read up front, no per-lane trip count -- the divergent loop above
-    // costs an exec-mask region and a register copy per accumulator and trip.
-    // PRE != nullptr: the row's entries were read once before the CG loop and live in registers (they do not change
-    // during a solve): no entry reads, and the neighbour reads no longer wait for them, inside the loop
-    template <int NFIX>
-    __device__ __forceinline__ void gather_fixed(const float* SRC, const int2* EN, int e0, float (&acc)[TPG], const int2* PRE = nullptr) const {
+    // the tail of the W_d^T rows: `tail_pairs` trips for EVERY lane (workgroup-uniform count, two entries = one 16-byte read
+    // per trip); a row that ends earlier holds {own row, weight 0} there -- consecutive lanes read consecutive rows, which
+    // cannot collide.  Same instruction slots as the per-lane loop it replaces (every wave of cfg2 holds a 9- or 10-entry
+    // row), but no exec-mask bookkeeping and the next pair of entries is requested ahead.
+    __device__ __forceinline__ void gather_tail(const float* SRC, float (&acc)[TPG]) const {
+        const float* base = SRC + t0;
+        const lds_i4* row = static_cast<const lds_i4*>(__builtin_assume_aligned(tail_t + (size_t)i * 2 * tail_pairs, 16));
+        lds_i4 nxt = row[0];                        // (the table is padded by one pair)
+        for (int j = 0; j < tail_pairs; ++j) {
+            const lds_i4 e2 = nxt;
+            float va[TPG], vb[TPG];
+            lds_load<TPG>(base + e2.x, va);
+            lds_load<TPG>(base + e2.z, vb);
+            nxt = row[j + 1];
+            const float wa = __int_as_float(e2.y), wb = __int_as_float(e2.w);
+            wacc<TPG>(wa, va, acc);
+            wacc<TPG>(wb, vb, acc);
+        }
+    }
+    // entries of this thread's rows -> registers (once per solve / operator application; they do not change)
+    template <int NE>
+    __device__ __forceinline__ void load_entries(const int2* EN, int e0, int2 (&en)[NE]) const {
+#pragma unroll
+        for (int u = 0; u < NE; ++u) en[u] = EN[e0 + u];
+    }
+    __device__ __forceinline__ void load_lead(int2 (&en)[LDS_NLEAD]) const { load_entries<LDS_NLEAD>(lead_t, i * LDS_NLEAD, en); }
+
+    // acc = W_u src / W_d src / W_d^T src on the own elements (src: an LDS image), zero-initialised here
+    __device__ __forceinline__ void mul_wu(const float* SRC, float (&acc)[TPG], const int2* PRE = nullptr) const {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
-#ifdef MGADMM_KO_NOGATHER
-        return;
-#endif
-        const float* base = SRC + t0;
-        int2 en[NFIX];
+        if constexpr (NU > 0) {
+            int2 en[NU];
+            if (PRE) {
 #pragma unroll
-        for (int u = 0; u < NFIX; ++u) en[u] = PRE ? PRE[u] : EN[e0 + u];
-#pragma unroll
-        for (int u = 0; u + 1 < NFIX; u += 2) {
-            float va[TPG], vb[TPG];
-            lds_load<TPG>(base + MG_ENX(en[u].x, u), va);
-            lds_load<TPG>(base + MG_ENX(en[u + 1].x, u + 1), vb);
-            const float wa = __int_as_float(en[u].y), wb = __int_as_float(en[u + 1].y);
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) acc[k] += wb * vb[k];
-        }
-        if (NFIX & 1) {
-            float va[TPG];
-            lds_load<TPG>(base + MG_ENX(en[NFIX - 1].x, NFIX - 1), va);
-            const float wa = __int_as_float(en[NFIX - 1].y);
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
-        }
+                for (int u = 0; u < NU; ++u) en[u] = PRE[u];
+            } else load_entries<NU>(en_u, u0, en);
+            gather_regs<NU>(SRC, en, acc);
+        } else gather(SRC, en_u, u0, u1, acc);
     }
-    // Ragged rows (W_d^T: the in-degree of a kNN graph varies): the first NLEAD entries are read up front and gathered
-    // together like a fixed row -- entries past the end of the row belong to the next row (or to the padding of the
-    // table: NLEAD entries), they are read but enter with weight 0 --, the rest of a long row in the paired loop of
-    // `gather`.  The sum runs in entry order (a weight-0 term adds exactly 0).  One LDS latency chain for a typical row
-    // instead of one per pair of entries.
-    template <int NLEAD>
-    __device__ __forceinline__ void gather_lead(const float* SRC, const int2* EN, int e0, int e1, float (&acc)[TPG], const int2* PRE = nullptr) const {
+    __device__ __forceinline__ void mul_wd(const float* SRC, float (&acc)[TPG], const int2* PRE = nullptr) const {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
-#ifdef MGADMM_KO_NOGATHER
-        return;
-#endif
-        const float* base = SRC + t0;
-        const int len = e1 - e0;
-        int2 en[NLEAD];
+        if constexpr (ND > 0) {
+            int2 en[ND];
+            if (PRE) {
 #pragma unroll
-        for (int u = 0; u < NLEAD; ++u) en[u] = PRE ? PRE[u] : EN[e0 + u];
-#pragma unroll
-        for (int u = 0; u < NLEAD; u += 2) {
-            float va[TPG], vb[TPG];
-            lds_load<TPG>(base + MG_ENX(en[u].x, u), va);
-            if (u + 1 < NLEAD) lds_load<TPG>(base + MG_ENX(en[u + 1].x, u + 1), vb);
-            const float wa = u < len ? __int_as_float(en[u].y) : 0.f;
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
-            if (u + 1 < NLEAD) {
-                const float wb = u + 1 < len ? __int_as_float(en[u + 1].y) : 0.f;
-#pragma unroll
-                for (int k = 0; k < TPG; ++k) acc[k] += wb * vb[k];
-            }
-        }
-        // (knock-out timing build MGADMM_KO_NOTAIL: rows cut after the leading entries -- this tail, a tenth of the gathers, costs a
-        // fifth of the cfg2 launch: every wave holds a 9- or 10-entry row and runs three dependent trips.  Measured and not
-        // kept: a second batch of four entries gathered like the leading ones -- 220 B of scratch, +18 %; the first pair of
-        // entries requested ahead of the leading rows -- no change)
-#ifdef MGADMM_KO_NOTAIL
-        if (false) {
-#else
-        if (len > NLEAD) {
-#endif
-            int e = e0 + NLEAD;
-            int2 na = EN[e], nb = EN[e + 1];
-            for (; e + 1 < e1; e += 2) {
-                const int2 ea = na, eb = nb;
-                float va[TPG], vb[TPG];
-                lds_load<TPG>(base + MG_ENX(ea.x, e - e0), va);
-                lds_load<TPG>(base + MG_ENX(eb.x, e - e0 + 1), vb);
-                na = EN[e + 2];
-                nb = EN[e + 3];
-                const float wa = __int_as_float(ea.y), wb = __int_as_float(eb.y);
-#pragma unroll
-                for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
-#pragma unroll
-                for (int k = 0; k < TPG; ++k) acc[k] += wb * vb[k];
-            }
-            if (e < e1) {
-                float va[TPG];
-                lds_load<TPG>(base + MG_ENX(na.x, e - e0), va);
-                const float wa = __int_as_float(na.y);
-#pragma unroll
-                for (int k = 0; k < TPG; ++k) acc[k] += wa * va[k];
-            }
-        }
+                for (int u = 0; u < ND; ++u) en[u] = PRE[u];
+            } else load_entries<ND>(en_d, d0, en);
+            gather_regs<ND>(SRC, en, acc);
+        } else gather(SRC, en_d, d0, d1, acc);
     }
-    // band (line-graph) stencils on the node's own time row
+    __device__ __forceinline__ void mul_wdt(const float* SRC, float (&acc)[TPG], const int2* PRET = nullptr) const {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
+        int2 en[LDS_NLEAD];
+        if (PRET) {
+#pragma unroll
+            for (int u = 0; u < LDS_NLEAD; ++u) en[u] = PRET[u];
+        } else load_lead(en);
+        gather_regs<LDS_NLEAD>(SRC, en, acc);
+        gather_tail(SRC, acc);
+    }
+    // band (line-graph) stencils on the row's own time axis
     __device__ __forceinline__ void band_back(const float* SRC, float (&acc)[TPG]) const {
         const float* row = SRC + i * TS;
 #pragma unroll
@@ -329,45 +362,41 @@ struct LdsCtx {
             }
         }
     }
-    // l = Lu(src): neighbours from SRC (LDS), the thread's own elements of src from registers (self)     ADMM.py:138-148
+    // l = Lu(src): neighbours from SRC (LDS, unshifted image), the thread's own elements of src from registers (self)  ADMM.py:138-148
     __device__ __forceinline__ void op_lu(const float* SRC, const float (&self)[TPG], float (&l)[TPG], const int2* PRE = nullptr) const {
         float acc[TPG];
-        if constexpr (NU > 0) gather_fixed<NU>(SRC, en_u, u0, acc, PRE);
-        else gather(SRC, en_u, u0, u1, acc);
+        mul_wu(SRC, acc, PRE);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = self[k] - acc[k];
     }
-    // l = Ldr(src)      ADMM.py:150-177
-    __device__ __forceinline__ void op_ldr(const float* SRC, const float (&self)[TPG], float (&l)[TPG], const int2* PRE = nullptr) const {
+    // l = Ldr(src), SRC: image stored with put<-1>      ADMM.py:150-177
+    __device__ __forceinline__ void op_ldr(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
         float acc[TPG];
         if constexpr (BAND) band_back(SRC, acc);
-        else if constexpr (ND > 0) gather_fixed<ND>(SRC, en_d, d0, acc, PRE);       // SRC: image stored with put<-1>
-        else gather(SRC, en_d, d0, d1, acc);
+        else mul_wd(SRC, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((k >= 1 || t0 >= 1) ? self[k] : 0.f) - acc[k];
     }
-    // l = Ldr_T(src)    ADMM.py:179-223 (q1: identity kept on the t=0 block)
-    __device__ __forceinline__ void op_ldrt(const float* SRC, const float (&self)[TPG], float (&l)[TPG], const int2* PRE = nullptr) const {
+    // l = Ldr_T(src), SRC: image stored with put<+1>    ADMM.py:179-223 (q1: identity kept on the t=0 block)
+    __device__ __forceinline__ void op_ldrt(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
         float acc[TPG];
-        if constexpr (!BAND) gather_lead<LDS_NLEAD>(SRC, en_t, t0e, t1e, acc, PRE);     // SRC: image stored with put<+1>
+        if constexpr (!BAND) mul_wdt(SRC, acc);
         else band_fwd(SRC, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((k > 0 || t0 > 0 || q1) ? self[k] : 0.f) - acc[k];
     }
     // own elements -> LDS image read by an operator that gathers time t + SH (SH = 0: Lu and the band stencils, -1: Ldr,
-    // +1: Ldr^T): index j of a node's row holds time j + SH, 0 outside [0,T)
-    // EDGE = false: the slot that holds time -1 resp. T (always 0) is left alone -- within one CG solve it is written
-    // once, with the first image, and no other store touches it
-    template <int SH, bool EDGE = true>
+    // +1: Ldr^T): index j of a row holds time j + SH, 0 outside [0,T).  (Only the operator applications outside the CG
+    // solves use the shifted forms; inside a solve lds_apply shifts the OWNERSHIP of q instead.)
+    template <int SH>
     __device__ __forceinline__ void put(float* DST, const float (&v)[TPG]) const {
-        if (!active) return;
         if constexpr (SH == 0 || BAND) {
             lds_store<TPG>(DST + own(), v);
         } else {
             float* row = DST + i * TS + t0 - SH;            // index of element k = 0
             // the 16-byte groups of the image that lie entirely inside this thread's elements go out as one aligned
             // ds_write_b128 each (SH = -1: v[3..6], v[7..10], ...; SH = +1: v[1..4], v[5..8], ...); the elements at the two
-            // ends are scalar stores (rows are 16-byte aligned, so scalar stores of 32 consecutive nodes hit 8 banks: 4-way)
+            // ends are scalar stores
             constexpr int K0 = SH < 0 ? 3 : 1;              // first element of the first whole group
             constexpr int NG = TPG % 4 == 0 ? (TPG - K0) / 4 : 0;
 #pragma unroll
@@ -376,33 +405,61 @@ struct LdsCtx {
                 q.x = v[K0 + 4 * j]; q.y = v[K0 + 4 * j + 1]; q.z = v[K0 + 4 * j + 2]; q.w = v[K0 + 4 * j + 3];
                 *static_cast<lds_f4*>(__builtin_assume_aligned(row + K0 + 4 * j, 16)) = q;
             }
-            // (the aligned pair among the remaining elements as one ds_write_b64 instead of the ds_write2_b32 the compiler
-            // forms: +2.3 % per launch, not kept)
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
                 if (k >= K0 && k < K0 + 4 * NG) continue;
                 const bool ok = SH < 0 ? (k < TPG - 1 || t0 + TPG < T) : (k > 0 || t0 > 0);   // index T resp. -1 does not exist
                 if (ok) row[k] = v[k];
             }
-            if (EDGE && SH < 0 && t0 == 0) DST[i * TS] = 0.f;                      // time -1
-            if (EDGE && SH > 0 && t0 + TPG == T) DST[i * TS + T - 1] = 0.f;        // time T
+            if (SH < 0 && t0 == 0) DST[i * TS] = 0.f;                      // time -1
+            if (SH > 0 && t0 + TPG == T) DST[i * TS + T - 1] = 0.f;        // time T
         }
     }
     // own elements -> HBM state vector (sample base already applied)
     __device__ __forceinline__ void putg(float* DST, const float (&v)[TPG]) const {
         if (active) {
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) DST[gl(k)] = v[k];
+            for (int k = 0; k < TPG; ++k) stg(DST, glb(k), v[k]);
         }
     }
 };
 
-// av = (A v) on the thread's own elements, for the vector v held in ctx.P (LDS; own elements also in v):
+// a per-thread operand vector parked in LDS across a CG solve (registers cannot hold it): element k of thread `tid`, 16-byte
+// pieces of consecutive threads adjacent (conflict-free ds_read_b128 / ds_write_b128)
+template <int TPG>
+__device__ __forceinline__ void slot_put(float* S, int tid, int nthr, const float (&v)[TPG]) {
+    if constexpr (TPG % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < TPG / 4; ++j) {
+            lds_f4 q;
+            q.x = v[4 * j]; q.y = v[4 * j + 1]; q.z = v[4 * j + 2]; q.w = v[4 * j + 3];
+            static_cast<lds_f4*>(__builtin_assume_aligned(S, 16))[j * nthr + tid] = q;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) S[k * nthr + tid] = v[k];
+    }
+}
+template <int TPG>
+__device__ __forceinline__ void slot_get(const float* S, int tid, int nthr, float (&v)[TPG]) {
+    if constexpr (TPG % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < TPG / 4; ++j) {
+            const lds_f4 q = static_cast<const lds_f4*>(__builtin_assume_aligned(S, 16))[j * nthr + tid];
+            v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) v[k] = S[k * nthr + tid];
+    }
+}
+
+// av = (A v) on the thread's own elements, for the vector v held in ctx.P (LDS, unshifted; own elements also in v):
 //   KIND 1: dc*v + c2*Ldr_T(Ldr v) ; KIND 2: dc*v + c2*Lu v ; KIND 0: dc*v
 // dc = diagonal coefficient of the own elements (H^T H or mask value, plus the rho/2 terms), see lds_diag.
 // Returns sum_k v_k * (A v)_k of the own elements.  Uses ctx.Q as scratch; contains a barrier for KIND 1.
-// Callers separate successive calls by barriers.
-template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND, bool EDGE = true>
+// Callers separate successive calls by barriers.  PRE / PRET: the thread's table rows in registers.
+template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND>
 __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, const float (&v)[TPG], float (&av)[TPG], const float (&dc)[TPG],
                                            float c2, const int2* PRE = nullptr, const int2* PRET = nullptr) {
     float l[TPG];
@@ -411,69 +468,65 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, c
     if (KIND == 1) {
         if constexpr (BAND) {
             float q[TPG];
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) q[k] = 0.f;
-            if (c.active) c.op_ldr(c.P, v, q, PRE);
+            c.op_ldr(c.P, v, q);
             if (SB) __syncthreads();           // single LDS vector (Q aliases P): every gather of p is done before q replaces it
-            c.template put<+1, EDGE || SB>(c.Q, q);      // SB: p and q alternate in one vector, their zero slots included
+            c.template put<+1>(c.Q, q);
             __syncthreads();
-            if (c.active) c.op_ldrt(c.Q, q, l, PRET);
+            c.op_ldrt(c.Q, q, l);
         } else {
             // SHIFTED OWNERSHIP of q = Ldr v.  Ldr reads time t-1 and Ldr^T time t+1, so with one partition of the time axis for
-            // both vectors either the store or the gather of an image is off by one float against the 16-byte groups (until
-            // mid round 2 the images were stored shifted: one ds_write_b128 + four scalar ds_write_b32 per store, the scalar
-            // stores of 32 consecutive nodes on 8 banks).  Here the thread that owns v at times t0 .. t0+TPG-1 computes and owns
-            // q at times t0+1 .. t0+TPG: its gather for q[t0+1+k] is the aligned run v[col][t0+k] of the UNSHIFTED image of v,
-            // it stores its q values as the aligned run at positions t0 .. (position j of the q image holds q[j+1]; time T
-            // does not exist: 0), and the Ldr^T gather for time t0+k reads q[col][t0+k+1] = that aligned run again.  Both
-            // images go out as whole ds_write_b128, every gather is an aligned run; the price is one scalar read per
-            // operator for the self term that sits in the neighbouring time group (v[t0+TPG] resp. q[t0]).  Same products in
-            // the same order: bitwise the former results.
+            // both vectors either the store or the gather of an image is off by one float against the 16-byte groups.  Here
+            // the thread that owns v at times t0 .. t0+TPG-1 computes and owns q at times t0+1 .. t0+TPG: its gather for
+            // q[t0+1+k] is the aligned run v[col][t0+k] of the UNSHIFTED image of v, it stores its q values as the aligned
+            // run at positions t0 .. (position j of the q image holds q[j+1]; time T does not exist: 0), and the Ldr^T
+            // gather for time t0+k reads q[col][t0+k+1] = that aligned run again.  Both images go out as whole
+            // ds_write_b128, every gather is an aligned run; the price is one read per operator for the self term that sits
+            // in the neighbouring time group (v[t0+TPG] resp. q[t0]) -- taken from its aligned 16-byte group (a scalar read
+            // of the same column of 32 consecutive rows is a 4-way bank conflict, the ds_read_b128 of consecutive rows none),
+            // through a clamped address and a select where the neighbouring group does not exist (no exec-mask region).
             float q[TPG];        // q[k] = (Ldr v)[t0 + k + 1]
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) q[k] = 0.f;
-            if (c.active) {
+            {
                 float acc[TPG];
-                if constexpr (ND > 0) c.template gather_fixed<ND>(c.P, c.en_d, c.d0, acc, PRE);
-                else c.gather(c.P, c.en_d, c.d0, c.d1, acc);
+                c.mul_wd(c.P, acc, PRE);
                 const bool has_next = c.t0 + TPG < c.T;
-                // v at the first time of the next group, own node: taken from its aligned 16-byte group (a scalar read of the
-                // same column of 32 consecutive rows is a 4-way bank conflict, the ds_read_b128 of consecutive rows none)
-                float vnext = 0.f;
-                if (has_next) {
-                    if constexpr (TPG % 4 == 0) vnext = static_cast<const lds_f4*>(__builtin_assume_aligned(c.P + c.own() + TPG, 16))[0].x;
-                    else vnext = c.P[c.own() + TPG];
-                }
+                float vnext;
+                if constexpr (TPG % 4 == 0) vnext = static_cast<const lds_f4*>(__builtin_assume_aligned(c.P + c.own() + (has_next ? TPG : 0), 16))[0].x;
+                else vnext = c.P[c.own() + (has_next ? TPG : 0)];
 #pragma unroll
                 for (int k = 0; k + 1 < TPG; ++k) q[k] = v[k + 1] - acc[k];
-                q[TPG - 1] = has_next ? vnext - acc[TPG - 1] : 0.f;
+                q[TPG - 1] = (has_next ? vnext : acc[TPG - 1]) - acc[TPG - 1];      // time T does not exist: 0
             }
             if (SB) __syncthreads();           // single LDS vector (Q aliases P): every gather of p is done before q replaces it
-            if (c.active) lds_store<TPG>(c.Q + c.own(), q);
+            lds_store<TPG>(c.Q + c.own(), q);
             __syncthreads();
-            if (c.active) {
+            {
                 float acc[TPG];
-                c.template gather_lead<LDS_NLEAD>(c.Q, c.en_t, c.t0e, c.t1e, acc, PRET);
-                float qprev = 0.f;          // q[t0]: the last value of the previous group (q[0] = 0), from its aligned 16-byte group
-                if (c.t0 > 0) {
-                    if constexpr (TPG % 4 == 0) qprev = static_cast<const lds_f4*>(__builtin_assume_aligned(c.Q + c.own() - 4, 16))[0].w;
-                    else qprev = c.Q[c.own() - 1];
-                }
-                l[0] = qprev - acc[0];
+                c.mul_wdt(c.Q, acc, PRET);
+                const bool has_prev = c.t0 > 0;
+                float qprev;          // q[t0]: the last value of the previous group (q[0] = 0)
+                if constexpr (TPG % 4 == 0) qprev = static_cast<const lds_f4*>(__builtin_assume_aligned(c.Q + c.own() - (has_prev ? 4 : 0), 16))[0].w;
+                else qprev = c.Q[c.own() - (has_prev ? 1 : 0)];
+                l[0] = (has_prev ? qprev : 0.f) - acc[0];
 #pragma unroll
                 for (int k = 1; k < TPG; ++k) l[k] = q[k - 1] - acc[k];
             }
         }
     } else if (KIND == 2) {
-        if (c.active) c.op_lu(c.P, v, l, PRE);
+        c.op_lu(c.P, v, l, PRE);
     }
-    float part = 0.f;
+    // av = dc * v (+ c2 * l);  v . av
+    if constexpr (TPG % 2 == 0) {
 #pragma unroll
-    for (int k = 0; k < TPG; ++k) {
-        av[k] = (KIND == 0) ? dc[k] * v[k] : dc[k] * v[k] + c2 * l[k];
-        part += v[k] * av[k];
+        for (int j = 0; j < TPG / 2; ++j) {
+            f2 r = mk2(dc[2 * j], dc[2 * j + 1]) * mk2(v[2 * j], v[2 * j + 1]);
+            if (KIND != 0) r = __builtin_elementwise_fma(mk2(c2, c2), mk2(l[2 * j], l[2 * j + 1]), r);
+            av[2 * j] = r.x; av[2 * j + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) av[k] = (KIND == 0) ? dc[k] * v[k] : __builtin_fmaf(c2, l[k], dc[k] * v[k]);
     }
-    return part;
+    return dot<TPG>(v, av);
 }
 // diagonal coefficient d + c1 of the own elements: d = dg[el] when dg != nullptr (mask values, global
 // memory), else [hth && t < t_in]   (ADMM.py:371-379: H^T H x resp. mask * x; ADMM.py:381-399: none)
@@ -481,7 +534,7 @@ template <int TPG, bool BAND, int NU, int ND>
 __device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND, NU, ND>& c, const float* dg, int hth, int t_in, float c1, float (&dc)[TPG]) {
 #pragma unroll
     for (int k = 0; k < TPG; ++k) {
-        const float d = dg ? (c.active ? dg[c.gl(k)] : 0.f) : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
+        const float d = dg ? (c.active ? ldg(dg, c.glb(k)) : 0.f) : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
         dc[k] = d + c1;
     }
 }
@@ -490,91 +543,64 @@ __device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND, NU, ND>& c, con
 // p in registers with a copy in LDS (ctx.P) for the neighbours' gathers, A p in registers.  x holds x0 on entry and the solution on exit.  dmask: diagonal
 // of the initial residual when a mask is given (global memory); the iterations always use [t<t_in]
 // (quirk Q2).  Returns the iteration count (k+1) or -1.  Entry requirement: no thread still reads P/Q.
+// Ghost threads enter with x = rhs = 0 and stay at 0.
 template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND>
 __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
-                      int hth, int t_in, float c1, float c2, int max_cg, double tol, float* ah, float* bh, int Bp,
+                      int hth, int t_in, float c1, float c2, int max_cg, double tol2, float* ah, float* bh, int Bp,
                       int* nonfinite) {
-    constexpr int SHP = 0;     // the image of the CG direction is stored unshifted for every operator (lds_apply: shifted ownership of q)
     float r[TPG], pv[TPG], av[TPG], dc[TPG];
-    c.template put<SHP>(c.P, x);
-    __syncthreads();
-    lds_diag<TPG, BAND, NU, ND>(c, dmask, hth, t_in, c1, dc);
-    (void)lds_apply<TPG, BAND, KIND, SB, NU, ND>(c, x, av, dc, c2);
-    if (dmask != nullptr) lds_diag<TPG, BAND, NU, ND>(c, nullptr, hth, t_in, c1, dc);     // quirk Q2: iterations use [t < t_in]
-    float part = 0.f;
-#pragma unroll
-    for (int k = 0; k < TPG; ++k) {
-        r[k] = c.active ? rhs[k] - av[k] : 0.f;
-        pv[k] = r[k];                    // p = r
-        part += r[k] * r[k];
-    }
-    float rr = br.sumf(part);            // barrier: every read of P (= x0) is done
-    c.template put<SHP, SB>(c.P, pv);
-    // entries of this thread's fixed-length row (W_d for the cLdr solves, W_u for the zu solve), once per solve
+    // the thread's table rows, once per solve: W_d and the leading W_d^T entries for the cLdr solves, W_u for the zu solve
     constexpr int NPRE = (KIND == 1 && !BAND && ND > 0) ? ND : ((KIND == 2 && NU > 0) ? NU : 0);
     int2 pre[NPRE > 0 ? NPRE : 1];
     if constexpr (NPRE > 0) {
-        const int2* EN = KIND == 1 ? c.en_d : c.en_u;
-        const int e0 = KIND == 1 ? c.d0 : c.u0;
-#pragma unroll
-        for (int u = 0; u < NPRE; ++u) pre[u] = EN[e0 + u];
+        if (KIND == 1) c.template load_entries<NPRE>(c.en_d, c.d0, pre);
+        else c.template load_entries<NPRE>(c.en_u, c.u0, pre);
     }
-    constexpr int NPRET = (KIND == 1 && !BAND) ? LDS_NLEAD : 0;      // ... and the leading entries of its W_d^T row
+    constexpr int NPRET = (KIND == 1 && !BAND) ? LDS_NLEAD : 0;
     int2 pret[NPRET > 0 ? NPRET : 1];
-    if constexpr (NPRET > 0) {
+    if constexpr (NPRET > 0) c.load_lead(pret);
+    c.template put<0>(c.P, x);
+    __syncthreads();
+    lds_diag<TPG, BAND, NU, ND>(c, dmask, hth, t_in, c1, dc);
+    (void)lds_apply<TPG, BAND, KIND, SB, NU, ND>(c, x, av, dc, c2, NPRE > 0 ? pre : nullptr, NPRET > 0 ? pret : nullptr);
+    if (dmask != nullptr) lds_diag<TPG, BAND, NU, ND>(c, nullptr, hth, t_in, c1, dc);     // quirk Q2: iterations use [t < t_in]
 #pragma unroll
-        for (int u = 0; u < NPRET; ++u) pret[u] = c.en_t[c.t0e + u];
+    for (int k = 0; k < TPG; ++k) {
+        r[k] = rhs[k] - av[k];
+        pv[k] = r[k];                    // p = r
     }
+    float part;
+    float rr = br.sumf(dot<TPG>(r, r));  // barrier: every read of P (= x0) is done
+    c.template put<0>(c.P, pv);
     int iters = -1;
     for (int it = 0; it < max_cg; ++it) {
         __syncthreads();                 // p complete in LDS
-        part = lds_apply<TPG, BAND, KIND, SB, NU, ND, false>(c, pv, av, dc, c2, NPRE > 0 ? pre : nullptr, NPRET > 0 ? pret : nullptr);
+        part = lds_apply<TPG, BAND, KIND, SB, NU, ND>(c, pv, av, dc, c2, NPRE > 0 ? pre : nullptr, NPRET > 0 ? pret : nullptr);
         const float pAp = br.sumf(part);         // barrier: every gather from P/Q of this iteration is done
-#ifdef MGADMM_KO_FIXED           // knock-out timing builds run a fixed number of iterations on made-up coefficients
-        const float alpha = 1e-3f + 0.f * pAp;
-#else
         // alpha, beta through v_rcp_f32 (1 ulp) instead of the correctly rounded division (a chain of ~10 dependent
         // instructions every thread waits for, twice per iteration: -2.9 % per launch).  The coefficients differ from
         // the IEEE quotient by at most 1.5 ulp -- below the rounding noise of the dot products they are formed from;
         // the streaming path keeps the IEEE division (its coefficients come from a separate tiny kernel).
         const float alpha = rr * __builtin_amdgcn_rcpf(pAp);
-#endif
-        part = 0.f;
-#pragma unroll
-        for (int k = 0; k < TPG; ++k) {
-            x[k] = x[k] + alpha * pv[k];
-            r[k] = r[k] - alpha * av[k];
-            part += r[k] * r[k];
-        }
-        const float rrn = br.sumf(part);
-#ifdef MGADMM_KO_FIXED
-        const float beta = 0.5f + 0.f * rrn;
-#else
+        axpy<TPG>(alpha, pv, x);
+        axpy<TPG>(-alpha, av, r);
+        const float rrn = br.sumf(dot<TPG>(r, r));
         const float beta = rrn * __builtin_amdgcn_rcpf(rr);
-#endif
         rr = rrn;
         if (ah != nullptr && threadIdx.x == 0) {
             ah[(size_t)it * Bp] = alpha;
             bh[(size_t)it * Bp] = beta;
         }
-#ifdef MGADMM_KO_FIXED
-#ifndef MGADMM_KO_ITERS
-#define MGADMM_KO_ITERS 0
-#endif
-        if (it + 1 == (MGADMM_KO_ITERS ? MGADMM_KO_ITERS : (KIND == 2 ? 11 : 17))) { iters = it + 1; break; }
-#else
         if (!(fabsf(rrn) <= 3.0e38f)) {       // NaN / Inf: report and stop this sample
             if (threadIdx.x == 0) *nonfinite = 1;
             break;
         }
-        if ((double)sqrtf(rrn) < tol) {
+        if ((double)rrn < tol2) {        // sqrt(r.r) < CG_tol (ADMM.py:360) without the square root
             iters = it + 1;
             break;
         }
-#endif
-#pragma unroll
-        for (int k = 0; k < TPG; ++k) pv[k] = r[k] + beta * pv[k];
-        c.template put<SHP, SB>(c.P, pv);
+        xpby<TPG>(r, beta, pv);
+        c.template put<0>(c.P, pv);
     }
     return iters;
 }
@@ -582,166 +608,203 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
 // MAXT: workgroup-size class the kernel is compiled for (register budget).  SB: single LDS vector (q = Ldr p replaces p
 // in place, one more barrier per cLdr application); with the 640-thread class it is compiled for TWO resident
 // workgroups per CU (5 waves per SIMD, <= 96 VGPRs): two samples in flight per CU overlap each other's barriers.
-// NU / ND > 0: every row of W_u / W_d holds exactly that many entries (a kNN table without pads): unrolled gathers.
-template <int TPG, bool BAND, int MAXT, bool SB, int NU = 0, int ND = 0>
-__global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(LdsArgs a) {
+// NU / ND > 0: every row of W_u / W_d holds exactly that many entries (a kNN table without pads): unrolled gathers, the
+// rows are read from the global image (L2) into registers once per solve and only the W_d^T tail table lives in LDS.
+// SLOTS: two more LDS vectors park per-thread operands across the solves (see the trip body).
+template <int TPG, bool BAND, int MAXT, bool SB, int NU = 0, int ND = 0, bool SLOTS = false>
+__global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(LdsArgs a_in) {
+    constexpr bool ENTG = NU > 0 && ND > 0;       // table rows from the global image
+    constexpr int NMRED = 12;                     // metric slots per wave (MGADMM_NMETRIC = 11)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     float* P = reinterpret_cast<float*>(lds_raw);
-    const int LN = a.N * a.TS;                                         // floats per LDS vector (TS % 4 == 0 or TS == T)
+    const int LN = a_in.NR * a_in.TS;                                  // floats per LDS vector (TS % 4 == 0 or TS == T)
     float* Q = SB ? P : P + LN;                                      // SB: one LDS vector serves p and q = Ldr p in turn
-    float* red = Q + LN + ((4 - (LN & 3)) & 3);                       // 16-byte aligned, 2 x 16 floats
-    int* csr = reinterpret_cast<int*>(red + 32);
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x;
+    float* red = Q + LN + ((4 - (LN & 3)) & 3);                       // 16-byte aligned: 2 x 16 floats of the CG reductions ...
+    float* mred = red + 32;                                           // ... and 16 x NMRED wave totals of the metrics
+    float* slot0 = mred + 16 * NMRED;
+    const int nthr = (int)blockDim.x;
+    float* slot1 = slot0 + (SLOTS ? nthr * TPG : 0);
+    int* img = reinterpret_cast<int*>(slot1 + (SLOTS ? nthr * TPG : 0));
+    int tid = threadIdx.x;
+    int b = blockIdx.x;
     // ADMM outer loop without host round trips: iterations are enqueued ahead of the host's look at the stop test, a launch
     // that follows the stopping iteration must leave the state alone (workgroup-uniform scalar load)
-    if (a.stop != nullptr && *a.stop != 0) return;
-    // diagnostic build (make EXTRA=-DMGADMM_PHASE_CLOCK): the per-sample metric slots receive the 100 MHz clock at the
-    // phase boundaries instead of the metrics (tools/lds_phase_clock.py)
-    auto stamp = [&](int m) {
-#ifdef MGADMM_PHASE_CLOCK
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        const unsigned long long tck = wall_clock64();
-        if (tid == 0) a.ps[(size_t)m * a.Bp + b] = (double)tck;
-#endif
-    };
-    // MGADMM_PHASE_CLOCK=2: slots 8..10 split the "batch 1 + RHS_x" phase instead of timing the last three phases
-    auto stamp_late = [&](int m) {
-#if defined(MGADMM_PHASE_CLOCK) && MGADMM_PHASE_CLOCK == 1
-        stamp(m);
-#endif
-    };
-    auto stamp_rhs = [&](int m) {
-#if defined(MGADMM_PHASE_CLOCK) && MGADMM_PHASE_CLOCK == 2
-        stamp(m);
-#endif
-    };
+    if (a_in.stop != nullptr && *a_in.stop != 0) return;
     // STAGGERED START.  Samples of one batch need (nearly) the same CG iteration counts, so the workgroups of a launch
     // run in lock step: all CUs store their results and request the next sample's operands at the same moment, while HBM
     // idles during the CG solves.  The workgroups of the first round (one per CU) start spread over `stagger_ticks`,
-    // their successors inherit the offset: the operand requests of different CUs no longer coincide (cfg2: 48 us of
-    // spread, -1.3 % per launch although the launch itself gets 48 us longer).
-    if (a.stagger_ticks > 0 && b < a.stagger_wgs) {
-        const unsigned long long wait = (unsigned long long)a.stagger_ticks * (unsigned)b / (unsigned)a.stagger_wgs;
+    // their successors inherit the offset: the operand requests of different CUs no longer coincide.
+    if (a_in.stagger_ticks > 0 && b < a_in.stagger_wgs) {
+        const unsigned long long wait = (unsigned long long)a_in.stagger_ticks * (unsigned)b / (unsigned)a_in.stagger_wgs;
         const unsigned long long t_in0 = wall_clock64();
         while (wall_clock64() - t_in0 < wait) __builtin_amdgcn_s_sleep(16);
     }
-    stamp(0);
+    // graph image -> LDS once per launch, eight words per thread in flight
+    {
+        const int* src = a_in.csr + a_in.lds_img0;
+        const int nimg = a_in.lds_img_ints;
+        for (int k0 = tid; k0 < nimg; k0 += 8 * nthr) {
+            int wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * nthr;
+                wv[u] = src[k < nimg ? k : nimg - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * nthr;
+                if (k < nimg) img[k] = wv[u];
+            }
+        }
+    }
+    for (int k = tid; k < 32 + 16 * NMRED; k += nthr) red[k] = 0.f;          // slots of non-existent waves must read as 0
+    {   // the ghosts' rows of both images: zeros
+        const int g0 = a_in.N * a_in.TS, gn = (a_in.NR - a_in.N) * a_in.TS;
+        for (int k = tid; k < gn; k += nthr) { P[g0 + k] = 0.f; Q[g0 + k] = 0.f; }
+    }
+    // SEVERAL ADMM ITERATIONS PER LAUNCH (a_in.J trips): a workgroup keeps its sample.  Every thread reads back only state it
+    // stored itself (no fence needed), the state of the samples in flight stays in L2 / Infinity Cache, x and gamma + rho phi
+    // pass from one trip to the next in registers, the graph image is copied once and the staggered start and the drain of
+    // the launch are paid once per J iterations.  The trip body must compile like a loop-free kernel: inside a loop the
+    // compiler hoists the launch arguments, every element address and the index arithmetic out of the loop and keeps them
+    // alive across the three solves (92 spilled SGPRs, 118 spilled VGPRs in round 3's first attempt).  So every trip re-reads
+    // its arguments from the kernarg segment through a copy of the segment pointer the optimiser cannot see through, and
+    // re-derives its indices from opaque copies of the thread and workgroup number.
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const LdsArgs __attribute__((address_space(4))) * KernargPtr;     // the kernarg segment: constant address space, scalar loads
+    KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();       // LdsArgs is the kernel's only argument: offset 0
+#else
+    const LdsArgs* kp = &a_in;                                                  // (host pass of the single-source compile)
+#endif
+    const int J = a_in.J;
+    float xc[TPG], vc[TPG];          // carried from trip to trip: the iterate and gamma + rho phi
+#pragma unroll
+    for (int k = 0; k < TPG; ++k) xc[k] = vc[k] = 0.f;
+    for (int trip = 0; trip < J; ++trip) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(kp));
+    asm volatile("" : "+v"(tid));
+    asm volatile("" : "+s"(b));
+    const LdsArgs __attribute__((address_space(4)))& a = *kp;
+#else
+    const LdsArgs& a = *kp;
+#endif
+    const bool first = a.first && trip == 0;      // phi = Ldr x0 is formed by the first trip of a cold start
     LdsCtx<TPG, BAND, NU, ND> c;
     c.T = a.T; c.TS = a.TS; c.N = a.N;
     c.active = tid < a.nthreads;
-    const int g = c.active ? tid / a.N : 0;
-    c.i = c.active ? tid - g * a.N : 0;
-    c.t0 = g * TPG;
+    {
+        const int g = c.active ? tid / a.N : 0;
+        c.ig = c.active ? tid - g * a.N : 0;
+        c.i = c.active ? c.ig : a.N + (tid - a.nthreads);
+        c.t0 = g * TPG;
+    }
     c.P = P; c.Q = Q;
     c.skip = a.skip; c.q1 = a.q1; c.band_w = a.band_w;
-    c.en_u = reinterpret_cast<const int2*>(csr + a.off_en_u);
-    c.en_d = reinterpret_cast<const int2*>(csr + a.off_en_d);
-    c.en_t = reinterpret_cast<const int2*>(csr + a.off_en_t);
-
+    c.tail_pairs = a.tail_pairs;
+    {
+        const int* tab = ENTG ? a.csr : img - a.lds_img0;          // where offsets into the image point
+        c.en_u = reinterpret_cast<const int2*>(tab + a.off_en_u);
+        c.en_d = reinterpret_cast<const int2*>(tab + a.off_en_d);
+        c.lead_t = reinterpret_cast<const int2*>(tab + a.off_lead_t);
+        c.tail_t = reinterpret_cast<const int2*>(img - a.lds_img0 + a.off_tail_t);
+    }
     const size_t sb = (size_t)b * a.TN;
-    const float* xo = a.x_old + sb;
-    float* xn = a.x_new + sb;
+    const float* xo = kp->xs[trip] + sb;          // iteration k reads xs[k] and writes xs[k+1]
+    float* xn = kp->xs[trip + 1] + sb;
     float *zu = a.zu + sb, *zd = a.zd + sb, *phi = a.phi + sb, *gam = a.gam + sb, *gu = a.gu + sb, *gd = a.gd + sb;
     const float* mk = a.mask ? a.mask + sb : nullptr;
     const int ty = a.mask ? a.T : a.t_in;
     const float* yb = a.y + (size_t)b * ty * a.N;
+    const bool has_phi = a.has_phi, has_zd = a.has_zd;
+    const float rho = a.rho, rho_u = a.rho_u, rho_d = a.rho_d;
 
+    // byte offsets of the own elements in a state vector, and in y (rows past its end: clamped, the value is masked)
+    unsigned off[TPG], offy[TPG];
+#pragma unroll
+    for (int k = 0; k < TPG; ++k) {
+        const int t = c.t0 + k;
+        off[k] = c.glb(k);
+        offy[k] = 4u * (unsigned)((t < ty ? t : ty - 1) * a.N + c.ig);
+    }
     // REQUEST of two operand vectors (TPG elements each per thread): 2 * TPG unconditional loads issued together and
     // waited for together; nothing crosses the fence, so the destination registers of one request are all a batch needs.
+    // (an operand the ablation does not use is read through a pointer to a vector that exists, ghosts read node 0, and the
+    // values are selected afterwards: branch-free)
     auto request2 = [&](const float* A, const float* B, const unsigned (&oa)[TPG], const unsigned (&ob)[TPG], float (&va)[TPG], float (&vb)[TPG]) {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) { va[k] = ldg(A, oa[k]); vb[k] = ldg(B, ob[k]); }
         MG_REQ_FENCE();
     };
+    auto request1 = [&](const float* A, const unsigned (&oa)[TPG], float (&va)[TPG]) {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) va[k] = ldg(A, oa[k]);
+        MG_REQ_FENCE();
+    };
 
-    // ---- batch 1: x_old and every operand of RHS_x (ADMM.py:556-564), requested FIRST, before the CSR image is copied:
-    // nothing else is live yet, so a request keeps its destination registers without spilling.
-    // The operands are read in REQUESTS of two vectors whose loads are unconditional and branch-free: an operand the
-    // ablation does not use is read through a pointer to a vector that exists, rows of y past t_in through a clamped
-    // index, idle threads read node 0, and the values are selected afterwards.  With the loads inside `if (flag)` regions
-    // (round 1 .. mid round 2) the compiler waited for every group of one or two loads: 40 dependent memory round trips,
-    // 19 us + 2 us for the CSR copy in the instrumented build (tools/lds_phase_clock.py), against 9 us for both now; a
-    // workgroup alone pulls the 221 KB in 6 us (tools/probe_batch_load.hip).  Production build: -1.9 % per launch.
+    // ---- operands of RHS_x (ADMM.py:556-564): o = (rho_u zu - gamma_u)/2 + (rho_d zd - gamma_d)/2 + H^T y, v = gamma + rho phi
+    // and x_old.  First trip of a launch: from the state in HBM.  Later trips: x and v arrive in registers, o from its LDS
+    // slot (SLOTS) or from the state this thread stored in the trip before.
     float x[TPG], o[TPG], v[TPG];
-    {
-        const bool use_v = a.has_phi && !a.first;
-        const float* zdp = a.has_zd ? zd : zu;
-        const float* gdp = a.has_zd ? gd : gu;
+    if (trip == 0 || !SLOTS) {
+        const float* zdp = has_zd ? zd : zu;
+        const float* gdp = has_zd ? gd : gu;
+        float ta[TPG], tb[TPG];
+        request2(zu, gu, off, off, ta, tb);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) o[k] = rhs_half(rho_u, ta[k], tb[k]);
+        request2(zdp, gdp, off, off, ta, tb);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) o[k] = has_zd ? o[k] + rhs_half(rho_d, ta[k], tb[k]) : o[k];
+        request1(yb, offy, ta);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) o[k] = c.active ? o[k] + ((c.t0 + k < ty) ? ta[k] : 0.f) : 0.f;
+    } else {
+        slot_get<TPG>(slot1, tid, nthr, o);
+    }
+    if (trip == 0) {
+        const bool use_v = has_phi && !first;
         const float* gamp = use_v ? gam : gu;
         const float* phip = use_v ? phi : zu;
-        unsigned off[TPG], offy[TPG];
-#pragma unroll
-        for (int k = 0; k < TPG; ++k) {
-            const int t = c.t0 + k;
-            off[k] = c.glb(k);
-            offy[k] = 4u * (unsigned)((t < ty ? t : ty - 1) * a.N + c.i);
-        }
         float ta[TPG], tb[TPG];
-        request2(zu, zdp, off, off, ta, tb);
-#pragma unroll
-        for (int k = 0; k < TPG; ++k) o[k] = a.has_zd ? (a.rho_u * ta[k] + a.rho_d * tb[k]) / 2.f : a.rho_u * ta[k] / 2.f;
-        request2(gu, gdp, off, off, ta, tb);
-#pragma unroll
-        for (int k = 0; k < TPG; ++k) o[k] = o[k] - (a.has_zd ? (ta[k] + tb[k]) / 2.f : ta[k] / 2.f);
-        request2(yb, xo, offy, off, ta, tb);
-#pragma unroll
-        for (int k = 0; k < TPG; ++k) {
-            o[k] = c.active ? o[k] + ((c.t0 + k < ty) ? ta[k] : 0.f) : 0.f;
-            x[k] = c.active ? tb[k] : 0.f;
-        }
         request2(gamp, phip, off, off, ta, tb);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) v[k] = (c.active && use_v) ? ta[k] + a.rho * tb[k] : 0.f;
-    }
-    stamp_rhs(8);
-    // CSR image -> LDS, eight words per thread in flight (one word per trip cost ten dependent L2 round trips, 3.6 us)
-    for (int k0 = tid; k0 < a.csr_ints; k0 += 8 * (int)blockDim.x) {
-        int wv[8];
+        for (int k = 0; k < TPG; ++k) v[k] = (c.active && use_v) ? ldrt_operand(rho, tb[k], ta[k]) : 0.f;
+        request1(xo, off, ta);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u * (int)blockDim.x;
-            wv[u] = a.csr[k < a.csr_ints ? k : a.csr_ints - 1];
-        }
+        for (int k = 0; k < TPG; ++k) x[k] = c.active ? ta[k] : 0.f;
+    } else {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + u * (int)blockDim.x;
-            if (k < a.csr_ints) csr[k] = wv[u];
-        }
+        for (int k = 0; k < TPG; ++k) { x[k] = xc[k]; v[k] = vc[k]; }
     }
-    if (tid < 32) red[tid] = 0.f;          // slots of non-existent waves must read as 0
-    __syncthreads();
-    stamp(1);
-    c.u0 = csr[a.off_rp_u + c.i]; c.u1 = csr[a.off_rp_u + c.i + 1];
-    c.d0 = c.d1 = c.t0e = c.t1e = 0;
-    if (!BAND) {
-        c.d0 = csr[a.off_rp_d + c.i]; c.d1 = csr[a.off_rp_d + c.i + 1];
-        c.t0e = csr[a.off_rp_t + c.i]; c.t1e = csr[a.off_rp_t + c.i + 1];
+    __syncthreads();          // graph image and zeroed rows (first trip); every LDS read of the previous trip is done
+    c.u0 = c.u1 = c.d0 = c.d1 = 0;
+    if constexpr (NU > 0) c.u0 = c.i * NU;
+    else { c.u0 = img[a.off_rp_u - a.lds_img0 + c.i]; c.u1 = img[a.off_rp_u - a.lds_img0 + c.i + 1]; }
+    if constexpr (!BAND) {
+        if constexpr (ND > 0) c.d0 = c.i * ND;
+        else { c.d0 = img[a.off_rp_d - a.lds_img0 + c.i]; c.d1 = img[a.off_rp_d - a.lds_img0 + c.i + 1]; }
     }
     BlockRed br;
-    br.red = red; br.par = 0; br.lane = tid & 63; br.wave = tid >> 6; br.nwaves = (blockDim.x + 63) >> 6;
-    // per-sample metric sums are reduced and stored as soon as they are known (keeps no accumulator alive
-    // across the CG solves); the whole-batch values are formed by k_batch_metrics
-    auto emit = [&](int m, double v, bool keep) {
-        const double sres = br.sum((float)v);
-#ifdef MGADMM_PHASE_CLOCK
-        if (tid == 0 && sres == 123.456) a.ps[(size_t)m * a.Bp + b] = sres;
-#else
-        if (tid == 0) a.ps[(size_t)m * a.Bp + b] = keep ? sres : 0.0;
-#endif
+    br.red = red; br.par = 0; br.lane = tid & 63; br.wave = tid >> 6; br.nwaves = (nthr + 63) >> 6;
+    // per-sample metric sums: wave totals (DPP) parked in LDS as soon as they are known (keeps no accumulator alive across
+    // the CG solves), combined in a fixed order at the end of the trip; the whole-batch values are formed by k_batch_metrics
+    auto mput = [&](int m, float val) {
+        const float w = wave_sum(val);
+        if (br.lane == 0) mred[br.wave * NMRED + m] = w;
     };
 
     // ---- first iteration only: phi = Ldr x0 (ADMM.py:541); the dual variables were filled by k_init_lds
-    if (a.has_phi && a.first) {
+    if (has_phi && first) {
         float ph[TPG];
-#pragma unroll
-        for (int k = 0; k < TPG; ++k) ph[k] = 0.f;
         c.template put<-1>(P, x);
         __syncthreads();
-        if (c.active) c.op_ldr(P, x, ph);
+        c.op_ldr(P, x, ph);
         c.putg(phi, ph);
+        float gq[TPG];
+        request1(gam, off, gq);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) v[k] = c.active ? gam[c.gl(k)] + a.rho * ph[k] : 0.f;
+        for (int k = 0; k < TPG; ++k) v[k] = c.active ? ldrt_operand(rho, ph[k], gq[k]) : 0.f;
         __syncthreads();
     }
 
@@ -751,206 +814,250 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         float l[TPG];
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = 0.f;
-        if (a.has_phi) {
+        if (has_phi) {
             c.template put<+1>(P, v);
             __syncthreads();
-            stamp_rhs(9);
-            if (c.active) c.op_ldrt(P, v, l);
+            c.op_ldrt(P, v, l);
             __syncthreads();
-            stamp_rhs(10);
         }
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) rhs[k] = c.active ? (a.has_phi ? l[k] / 2.f + o[k] : o[k]) : 0.f;
+        for (int k = 0; k < TPG; ++k) rhs[k] = has_phi ? l[k] * 0.5f + o[k] : o[k];
     }
+    if (SLOTS) slot_put<TPG>(slot0, tid, nthr, x);         // x_old, for the x-shift metric after the solve
     float* ah = a.record ? a.alpha_hist + b : nullptr;
     float* bh = a.record ? a.beta_hist + b : nullptr;
-    const size_t hstride = (size_t)a.max_cg * a.Bp;
+    int max_cg = a.max_cg;
+    double tol = a.cg_tol2;                    // the solves compare r.r with CG_tol^2
+    int Bp = a.Bp;
+    int* nonfinite = a.nonfinite;
+    MG_PIN_S(max_cg); MG_PIN_S(tol); MG_PIN_S(Bp); MG_PIN_S(nonfinite); MG_PIN_S(ah); MG_PIN_S(bh);
+    const size_t hstride = (size_t)max_cg * Bp;
 
-    stamp(2);
     // ---- x solve (ADMM.py:571)
     int itx;
-    if (a.lhsx_kind == 1) itx = lds_cg<TPG, BAND, 1, SB, NU, ND>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, a.cx2, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
-    else itx = lds_cg<TPG, BAND, 0, SB, NU, ND>(c, br, x, rhs, mk, 1, a.t_in, a.cx1, 0.f, a.max_cg, a.cg_tol, ah, bh, a.Bp, a.nonfinite);
-    stamp(3);
+    {
+        float cx1 = a.cx1, cx2 = a.cx2;
+        int t_in = a.t_in;
+        MG_PIN_S(cx1); MG_PIN_S(cx2); MG_PIN_S(t_in);
+        if (a.lhsx_kind == 1) itx = lds_cg<TPG, BAND, 1, SB, NU, ND>(c, br, x, rhs, mk, 1, t_in, cx1, cx2, max_cg, tol, ah, bh, Bp, nonfinite);
+        else itx = lds_cg<TPG, BAND, 0, SB, NU, ND>(c, br, x, rhs, mk, 1, t_in, cx1, 0.f, max_cg, tol, ah, bh, Bp, nonfinite);
+    }
     c.putg(xn, x);
 
-    // ---- batch 2: operands of the x metrics and of the zu solve
-    float z[TPG], gq[TPG];
+    // ---- x metrics, operands of the zu solve
+    float z[TPG];
     {
-        float xold[TPG], yv[TPG], mv[TPG];
-#pragma unroll
-        for (int k = 0; k < TPG; ++k) {
-            xold[k] = yv[k] = mv[k] = z[k] = gq[k] = 0.f;
-            if (c.active) {
-                const int e = c.gl(k);
-                const int t = c.t0 + k;
-                xold[k] = xo[e];
-                if (mk) { mv[k] = mk[e]; yv[k] = yb[t * a.N + c.i]; }
-                else if (t < a.t_in) yv[k] = yb[t * a.N + c.i];
-                z[k] = zu[e];
-                gq[k] = gu[e];
-            }
+        float xold[TPG], yv[TPG], gq[TPG];
+        if (SLOTS) {
+            request2(yb, gu, offy, off, yv, gq);
+            slot_get<TPG>(slot0, tid, nthr, xold);
+            slot_put<TPG>(slot0, tid, nthr, x);            // x_new, for the updates after the zu / zd solves
+        } else {
+            request2(yb, gu, offy, off, yv, gq);
+            request1(xo, off, xold);
         }
-        double m_xshift = 0, m_rec = 0;
-        if (c.active) {
+        request1(zu, off, z);
+        float m_xshift = 0.f, m_rec = 0.f;
+        if (mk) {
+            float mv[TPG];
+            request1(mk, off, mv);
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
-                const int t = c.t0 + k;
-                const double dx = (double)x[k] - (double)xold[k];
-                m_xshift += dx * dx;
-                if (mk) {
-                    const double e = (double)(x[k] * mv[k] - yv[k]);
-                    m_rec += e * e;
-                } else if (t < a.t_in) {
-                    const double e = (double)(x[k] - yv[k]);
-                    m_rec += e * e;
-                }
+                const float e = c.active ? x[k] * mv[k] - yv[k] : 0.f;
+                m_rec += e * e;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) {
+                const float e = (c.active && c.t0 + k < ty) ? x[k] - yv[k] : 0.f;
+                m_rec += e * e;
             }
         }
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) rhs[k] = c.active ? gq[k] / 2.f + a.rho_u / 2.f * x[k] : 0.f;     // x = the x_new just stored
-        emit(MGADMM_M_XSHIFT, m_xshift, true);
-        emit(MGADMM_M_RECOVER, m_rec, true);
+        for (int k = 0; k < TPG; ++k) {
+            const float dx = c.active ? x[k] - xold[k] : 0.f;
+            m_xshift += dx * dx;
+            z[k] = c.active ? z[k] : 0.f;
+            gq[k] = c.active ? gq[k] : 0.f;
+            rhs[k] = gq[k] * 0.5f + rho_u * 0.5f * x[k];      // x = the x_new just stored
+        }
+        mput(MGADMM_M_XSHIFT, m_xshift);
+        mput(MGADMM_M_RECOVER, m_rec);
+        if (SLOTS) {                       // gamma_u and the old zu wait in LDS for the update after the solve
+            slot_put<TPG>(slot1, tid, nthr, gq);
+            if (!SB) lds_store<TPG>(Q + c.own(), z);        // (the zu solve does not use Q)
+        }
     }
 
-    stamp(4);
     // ---- zu solve + gamma_u update (ADMM.py:579-580, 595)
-    int itzu = lds_cg<TPG, BAND, 2, SB, NU, ND>(c, br, z, rhs, nullptr, 0, 0, a.rho_u / 2.f, a.mu_u, a.max_cg, a.cg_tol, ah ? ah + hstride : nullptr,
-                                        bh ? bh + hstride : nullptr, a.Bp, a.nonfinite);
-    stamp(5);
-    // ---- batch 3: x_new, old zu, gamma_u for the update + the operands of the next phase (zd solve, or the phi prox)
+    int itzu;
+    {
+        float c1 = rho_u * 0.5f, c2 = a.mu_u;
+        MG_PIN_V(c1); MG_PIN_S(c2);
+        itzu = lds_cg<TPG, BAND, 2, SB, NU, ND>(c, br, z, rhs, nullptr, 0, 0, c1, c2, max_cg, tol, ah ? ah + hstride : nullptr,
+                                                 bh ? bh + hstride : nullptr, Bp, nonfinite);
+    }
     float xr[TPG], zn[TPG], gn[TPG];
     {
         float zo[TPG], gv[TPG];
+        // operands of the next phase (zd solve, or the phi prox)
+        const float* znp = has_zd ? zd : (has_phi ? phi : zu);
+        const float* gnp = has_zd ? gd : (has_phi ? gam : gu);
+        request2(znp, gnp, off, off, zn, gn);
+        if (SLOTS && !SB) {
+            slot_get<TPG>(slot0, tid, nthr, xr);
+            slot_get<TPG>(slot1, tid, nthr, gv);
+            lds_load<TPG>(Q + c.own(), zo);
+        } else {
+            request2(zu, gu, off, off, zo, gv);
+            if (SLOTS) slot_get<TPG>(slot0, tid, nthr, xr);
+            else request1(xn, off, xr);
+        }
+        float m_pri = 0.f, m_dual = 0.f;
+        float ou[TPG];
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
-            xr[k] = zn[k] = gn[k] = zo[k] = gv[k] = 0.f;
-            if (c.active) {
-                const int e = c.gl(k);
-                xr[k] = xn[e];
-                zo[k] = zu[e];
-                gv[k] = gu[e];
-                if (a.has_zd) { zn[k] = zd[e]; gn[k] = gd[e]; }
-                else if (a.has_phi) { zn[k] = phi[e]; gn[k] = gam[e]; }
-            }
+            xr[k] = c.active ? xr[k] : 0.f;
+            zo[k] = c.active ? zo[k] : 0.f;
+            gv[k] = c.active ? gv[k] : 0.f;
+            zn[k] = c.active ? zn[k] : 0.f;
+            gn[k] = c.active ? gn[k] : 0.f;
+            const float pz = xr[k] - z[k], dz = z[k] - zo[k];
+            m_pri += pz * pz;
+            m_dual += dz * dz;
+            gv[k] = gv[k] + rho_u * pz;
+            ou[k] = rhs_half(rho_u, z[k], gv[k]);
         }
-        double m_prizu = 0, m_dualzu = 0;
-        if (c.active) {
-#pragma unroll
-            for (int k = 0; k < TPG; ++k) {
-                const int e = c.gl(k);
-                const float pz = xr[k] - z[k], dz = z[k] - zo[k];
-                m_prizu += (double)pz * pz;
-                m_dualzu += (double)dz * dz;
-                zu[e] = z[k];
-                gu[e] = gv[k] + a.rho_u * pz;
-            }
-        }
-        emit(MGADMM_M_PRI_ZU, m_prizu, true);
-        emit(MGADMM_M_DUAL_ZU, m_dualzu, true);
+        c.putg(zu, z);
+        c.putg(gu, gv);
+        if (SLOTS) slot_put<TPG>(slot1, tid, nthr, ou);
+        mput(MGADMM_M_PRI_ZU, m_pri);
+        mput(MGADMM_M_DUAL_ZU, m_dual);
     }
     // ---- zd solve + gamma_d update (ADMM.py:586-588, 597)
     int itzd = 0;
-    if (a.has_zd) {
+    if (has_zd) {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
             z[k] = zn[k];
-            rhs[k] = c.active ? gn[k] / 2.f + a.rho_d / 2.f * xr[k] : 0.f;
+            rhs[k] = gn[k] * 0.5f + rho_d * 0.5f * xr[k];
         }
-        stamp(6);
-        itzd = lds_cg<TPG, BAND, 1, SB, NU, ND>(c, br, z, rhs, nullptr, 0, 0, a.rho_d / 2.f, a.mu_d2, a.max_cg, a.cg_tol,
-                              ah ? ah + 2 * hstride : nullptr, bh ? bh + 2 * hstride : nullptr, a.Bp, a.nonfinite);
-        stamp(7);
-        // ---- batch 4: x_new, old zd, gamma_d + the operands of the phi prox
+        {
+            float c1 = rho_d * 0.5f, c2 = a.mu_d2;
+            MG_PIN_V(c1); MG_PIN_S(c2);
+            itzd = lds_cg<TPG, BAND, 1, SB, NU, ND>(c, br, z, rhs, nullptr, 0, 0, c1, c2, max_cg, tol, ah ? ah + 2 * hstride : nullptr,
+                                                     bh ? bh + 2 * hstride : nullptr, Bp, nonfinite);
+        }
         float zo[TPG], gv[TPG];
+        request2(zd, gd, off, off, zo, gv);
+        if (has_phi) request2(phi, gam, off, off, zn, gn);
+        if (SLOTS) slot_get<TPG>(slot0, tid, nthr, xr);
+        else request1(xn, off, xr);
+        float m_pri = 0.f, m_dual = 0.f;
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
-            xr[k] = zo[k] = gv[k] = zn[k] = gn[k] = 0.f;
-            if (c.active) {
-                const int e = c.gl(k);
-                xr[k] = xn[e];
-                zo[k] = zd[e];
-                gv[k] = gd[e];
-                if (a.has_phi) { zn[k] = phi[e]; gn[k] = gam[e]; }
-            }
+            xr[k] = c.active ? xr[k] : 0.f;
+            zo[k] = c.active ? zo[k] : 0.f;
+            gv[k] = c.active ? gv[k] : 0.f;
+            zn[k] = c.active ? zn[k] : 0.f;
+            gn[k] = c.active ? gn[k] : 0.f;
+            const float pz = xr[k] - z[k], dz = z[k] - zo[k];
+            m_pri += pz * pz;
+            m_dual += dz * dz;
+            gv[k] = gv[k] + rho_d * pz;
         }
-        double m_prizd = 0, m_dualzd = 0;
-        if (c.active) {
+        c.putg(zd, z);
+        c.putg(gd, gv);
+        if (SLOTS) {                        // o of the next trip: (o_u + o_d) + H^T y
+            float ou[TPG], yv[TPG];
+            request1(yb, offy, yv);
+            slot_get<TPG>(slot1, tid, nthr, ou);
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) {
-                const int e = c.gl(k);
-                const float pz = xr[k] - z[k], dz = z[k] - zo[k];
-                m_prizd += (double)pz * pz;
-                m_dualzd += (double)dz * dz;
-                zd[e] = z[k];
-                gd[e] = gv[k] + a.rho_d * pz;
-            }
+            for (int k = 0; k < TPG; ++k) ou[k] = c.active ? (ou[k] + rhs_half(rho_d, z[k], gv[k])) + ((c.t0 + k < ty) ? yv[k] : 0.f) : 0.f;
+            slot_put<TPG>(slot1, tid, nthr, ou);
         }
-        emit(MGADMM_M_PRI_ZD, m_prizd, true);
-        emit(MGADMM_M_DUAL_ZD, m_dualzd, true);
+        mput(MGADMM_M_PRI_ZD, m_pri);
+        mput(MGADMM_M_DUAL_ZD, m_dual);
     } else {
-        emit(MGADMM_M_PRI_ZD, 0.0, false);
-        emit(MGADMM_M_DUAL_ZD, 0.0, false);
+        if (SLOTS) {                        // o of the next trip: o_u + H^T y
+            float ou[TPG], yv[TPG];
+            request1(yb, offy, yv);
+            slot_get<TPG>(slot1, tid, nthr, ou);
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) ou[k] = c.active ? ou[k] + ((c.t0 + k < ty) ? yv[k] : 0.f) : 0.f;
+            slot_put<TPG>(slot1, tid, nthr, ou);
+        }
+        mput(MGADMM_M_PRI_ZD, 0.f);
+        mput(MGADMM_M_DUAL_ZD, 0.f);
     }
 
     // ---- phi prox, gamma update, Ldr/Lu based diagnostics (ADMM.py:600-606, 619, 627-637); xr = x_new, zn = phi_old, gn = gamma
-    double m_priphi = 0, m_dualphi = 0, m_dgtv = 0, m_dglr = 0, m_glr = 0;
-    stamp_late(8);
+    float m_priphi = 0.f, m_dualphi = 0.f, m_dgtv = 0.f, m_dglr = 0.f, m_glr = 0.f;
     __syncthreads();          // every LDS read of the last CG is done
     c.template put<-1>(P, xr);        // read by Ldr
     if (!SB) c.template put<0>(Q, xr);   // read by Lu (GLR); SB: Q aliases P, see below
     __syncthreads();
-    if (c.active) {
+    {
         float l[TPG];
         c.op_ldr(P, xr, l);
-        const float thr = a.mu_d1 / a.rho;
+        const float thr = a.mu_d1 / rho;
+        float pn[TPG], gnew[TPG];
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
-            m_dgtv += fabs((double)l[k]);
-            m_dglr += (double)l[k] * l[k];
-            if (a.has_phi) {
-                const int e = c.gl(k);
-                const float gv = gn[k];
-                const float s = l[k] - gv / a.rho;
-                const float u = fabsf(s) - thr;
-                const float pn = (u > 0.f) ? (s > 0.f ? u : -u) : 0.f;
-                const float dd = pn - l[k], dp = pn - zn[k];
-                m_priphi += (double)dd * dd;
-                m_dualphi += (double)dp * dp;
-                phi[e] = pn;
-                gam[e] = gv + a.rho * dd;
-            }
+            m_dgtv += fabsf(l[k]);
+            m_dglr += l[k] * l[k];
+            const float gv = gn[k];
+            const float s = l[k] - gv / rho;
+            const float u = fabsf(s) - thr;
+            pn[k] = (u > 0.f) ? (s > 0.f ? u : -u) : 0.f;
+            const float dd = pn[k] - l[k], dp = pn[k] - zn[k];
+            m_priphi += dd * dd;
+            m_dualphi += dp * dp;
+            gnew[k] = gv + rho * dd;
+            vc[k] = has_phi ? ldrt_operand(rho, pn[k], gnew[k]) : 0.f;       // v of the next trip (ghosts: gn = zn = l = 0 -> 0)
+            xc[k] = xr[k];                                                    // x_old of the next trip
+        }
+        if (has_phi) {
+            c.putg(phi, pn);
+            c.putg(gam, gnew);
         }
         if (!SB) {
             c.op_lu(Q, xr, l);
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) m_glr += (double)xr[k] * (double)l[k];
+            for (int k = 0; k < TPG; ++k) m_glr += xr[k] * l[k];
         }
     }
     if (SB) {                 // one LDS vector: the unshifted image replaces the shifted one after every Ldr gather is done
         __syncthreads();
         c.template put<0>(P, xr);
         __syncthreads();
-        if (c.active) {
-            float l[TPG];
-            c.op_lu(P, xr, l);
+        float l[TPG];
+        c.op_lu(P, xr, l);
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) m_glr += (double)xr[k] * (double)l[k];
-        }
+        for (int k = 0; k < TPG; ++k) m_glr += xr[k] * l[k];
     }
-
-    stamp_late(9);
-    emit(MGADMM_M_PRI_PHI, m_priphi, a.has_phi);
-    emit(MGADMM_M_DUAL_PHI, m_dualphi, a.has_phi);
-    emit(MGADMM_M_DGTV, m_dgtv, a.has_phi);
-    emit(MGADMM_M_DGLR, m_dglr, a.has_zd);
-    emit(MGADMM_M_GLR, m_glr, true);
-    stamp_late(10);
+    mput(MGADMM_M_PRI_PHI, has_phi ? m_priphi : 0.f);
+    mput(MGADMM_M_DUAL_PHI, has_phi ? m_dualphi : 0.f);
+    mput(MGADMM_M_DGTV, has_phi ? m_dgtv : 0.f);
+    mput(MGADMM_M_DGLR, has_zd ? m_dglr : 0.f);
+    mput(MGADMM_M_GLR, m_glr);
+    __syncthreads();          // wave totals of every metric are in LDS; the P / Q reads of this trip are done
+    if (tid < MGADMM_NMETRIC) {
+        // fixed association: four partial sums over the waves w = j, j+4, j+8, j+12, then (s0 + s1) + (s2 + s3)
+        float sj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            sj[j] = (mred[j * NMRED + tid] + mred[(j + 4) * NMRED + tid]) + (mred[(j + 8) * NMRED + tid] + mred[(j + 12) * NMRED + tid]);
+        double* ps = a.ps + (size_t)trip * MGADMM_NMETRIC * a.Bp;     // per-sample metric sums of this iteration
+        ps[(size_t)tid * a.Bp + b] = (double)((sj[0] + sj[1]) + (sj[2] + sj[3]));
+    }
     if (tid == 0) {
-        a.cg_iters[b] = itx;
-        a.cg_iters[a.Bp + b] = itzu;
-        a.cg_iters[2 * a.Bp + b] = itzd;
+        int* const cgi = a.cg_iters + (size_t)trip * 3 * a.Bp;
+        cgi[b] = itx;
+        cgi[a.Bp + b] = itzu;
+        cgi[2 * a.Bp + b] = itzd;
     }
+    }       // trips
 }
 
 // initial state in sample-major layout: x0 (regression), zu = zd = x0, gamma* = 0.1   (ADMM.py:528-544)

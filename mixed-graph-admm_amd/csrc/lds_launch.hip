@@ -22,9 +22,9 @@ int allow_lds(const void* fn, int bytes) {
     return MGADMM_OK;
 }
 
-template <int TPG, bool BAND, int MAXT, bool SB, int NU = 0, int ND = 0>
+template <int TPG, bool BAND, int MAXT, bool SB, int NU = 0, int ND = 0, bool SLOTS = false>
 int launch(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st) {
-    auto fn = k_admm_lds<TPG, BAND, MAXT, SB, NU, ND>;
+    auto fn = k_admm_lds<TPG, BAND, MAXT, SB, NU, ND, SLOTS>;
     MG_TRY(allow_lds((const void*)fn, 160 * 1024));
     hipLaunchKernelGGL(fn, dim3(B), dim3(L.block), L.lds_bytes, st, a);
     MG_HIP(hipGetLastError());
@@ -39,6 +39,14 @@ int launch_b(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st) {
 }  // namespace
 
 int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st) {
+    if (a.J < 1 || a.J > LDS_MAXJ || a.NR * 1 < a.N || L.block - a.nthreads != a.NR - a.N) {
+        mg_set_error("lds: launch geometry (J %d, rows %d for %d nodes, %d of %d threads own elements)", a.J, a.NR, a.N, a.nthreads, L.block);
+        return MGADMM_ERR_INVALID;
+    }
+    if ((L.uniform45 && !a.band) != (L.tpg == 8 && L.uniform45 && !a.band && !L.sb && L.maxt == 1024)) {
+        mg_set_error("lds: the uniform-row instance exists for TPG 8 only");
+        return MGADMM_ERR_UNSUPPORTED;
+    }
     if (L.sb) {
         if (L.tpg == 12 && L.maxt == 640) return launch_b<12, 640, true>(L, a, B, st);
         if (L.tpg == 8 && L.maxt == 1024) return launch_b<8, 1024, true>(L, a, B, st);
@@ -53,7 +61,8 @@ int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st
         case 4: return launch_b<4, 1024, false>(L, a, B, st);
         case 6: return launch_b<6, 1024, false>(L, a, B, st);
         case 8:
-            if (L.uniform45 && !a.band) return launch<8, false, 1024, false, 4, 5>(L, a, B, st);
+            if (L.uniform45 && !a.band)
+                return L.slots ? launch<8, false, 1024, false, 4, 5, true>(L, a, B, st) : launch<8, false, 1024, false, 4, 5, false>(L, a, B, st);
             return launch_b<8, 1024, false>(L, a, B, st);
         case 12: return launch_b<12, 1024, false>(L, a, B, st);
     }

@@ -2,8 +2,9 @@
 
 SYNC (MGADMM_LDS_ASYNC=0): one stream, the host tests the stop criterion (ADMM.py:645-646) after every iteration.
 DEVSTOP (check_stop): the stop test runs on the device, later launches return at their guard, the host looks late.
-OVERLAP (fixed iteration count): the whole-batch metric kernels run on a helper stream beside the next k_admm_lds launch
-(x rotates through three buffers).
+CHUNKS (fixed iteration count): one k_admm_lds launch runs J iterations on every sample (MGADMM_LDS_CHUNK, default 7; the
+workgroup keeps its sample), every iterate goes to a buffer of its own and the whole-batch metric kernels of a chunk run on a
+helper stream beside the launch of the next chunk.
 Compared: x, the exported state, every history list and the iteration count -- bit for bit -- plus the stop iteration against
 the oracle (float64 restatement of the reference)."""
 import os
@@ -20,9 +21,11 @@ pytestmark = pytest.mark.gpu
 LISTS = ("p_res_list", "d_res_list", "x_shift_list", "GLR_list", "DGTV_list", "DGLR_list", "recover_list")
 
 
-def _run(env, meta, abl, task, B, check_stop, iters, tol=None):
+def _run(env, meta, abl, task, B, check_stop, iters, tol=None, chunk=None):
     old = os.environ.get("MGADMM_LDS_ASYNC")
     os.environ["MGADMM_LDS_ASYNC"] = env          # read when the solver handle is created
+    if chunk is not None:
+        os.environ["MGADMM_LDS_CHUNK"] = str(chunk)
     try:
         y, mask = case_inputs(meta, task, np.float32)
         rng = np.random.default_rng(5)
@@ -46,6 +49,7 @@ def _run(env, meta, abl, task, B, check_stop, iters, tol=None):
         blk.close()
         return out
     finally:
+        os.environ.pop("MGADMM_LDS_CHUNK", None)
         if old is None:
             os.environ.pop("MGADMM_LDS_ASYNC", None)
         else:
@@ -76,6 +80,19 @@ def test_fixed_iteration_count_overlapped_equals_synchronous(abl, task, B):
         a = _run("0", meta, abl, task, B, False, iters)
         b = _run("1", meta, abl, task, B, False, iters)
         assert a["n"] == iters
+        _same(a, b)
+
+
+@pytest.mark.parametrize("abl,task,B", [("None", "pred", 3), ("None", "pred", 300), ("DGLR", "mask", 70), ("DGTV", "pred", 130)])
+def test_several_iterations_per_launch_equal_one_per_launch(abl, task, B):
+    """Chunks of J iterations per launch (the workgroup keeps its sample, iterates in a ring of 2 (J - 1) + 3 buffers) against the
+    synchronous one-iteration-per-launch loop: iteration counts that are a multiple of J, leave a remainder, fit one chunk,
+    and need more chunks than there are buffer sets."""
+    meta = load_golden("g4_meta.npz")
+    for iters, chunk in ((1, 7), (5, 2), (6, 3), (7, 7), (8, 7), (16, 5), (23, 4)):
+        a = _run("0", meta, abl, task, B, False, iters)
+        b = _run("1", meta, abl, task, B, False, iters, chunk=chunk)
+        assert a["n"] == b["n"] == iters
         _same(a, b)
 
 

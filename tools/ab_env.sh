@@ -7,7 +7,7 @@ for r in $(seq 1 $rounds); do
     python - "$var=$v" <<'P'
 import json, sys
 d = json.loads(open("/tmp/ab_bench.log").read().strip().splitlines()[-1])
-print(f"{sys.argv[1]:34s} {d['value']:10.0f} {d['ms_per_step']:8.4f} {d['roofline']['avg_launch_us']:8.1f}  cg {d['config']['mean_cg_iters_x_zu_zd']}", flush=True)
+print(f"{sys.argv[1]:34s} {d['value']:10.0f} {d['ms_per_step']:8.4f} {d['roofline']['avg_iteration_us']:8.1f}  cg {d['config']['mean_cg_iters_x_zu_zd']}", flush=True)
 P
   done
 done

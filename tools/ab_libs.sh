@@ -8,7 +8,7 @@ for r in $(seq 1 $rounds); do
     python - "$lib" <<'P'
 import json, sys
 d = json.loads(open("/tmp/ab_bench.log").read().strip().splitlines()[-1])
-print(f"{sys.argv[1]:40s} {d['value']:10.0f} {d['ms_per_step']:8.4f} {d['roofline']['avg_launch_us']:8.1f}", flush=True)
+print(f"{sys.argv[1]:40s} {d['value']:10.0f} {d['ms_per_step']:8.4f} {d['roofline']['avg_iteration_us']:8.1f}", flush=True)
 P
   done
 done
