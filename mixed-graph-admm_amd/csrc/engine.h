@@ -85,7 +85,7 @@ struct Engine : EngineBase {
         bool ok = false;
         int G = 0, TPG = 0, TS = 0, nthreads = 0, block = 0, NR = 0, csr_ints = 0, maxt = 1024, sb = 0, uniform45 = 0, slots = 0;
         int tail_pairs = 0, lds_img0 = 0, lds_img_ints = 0;
-        int off_rp_u = 0, off_rp_d = 0, off_en_u = 0, off_en_d = 0, off_lead_t = 0, off_tail_t = 0;
+        int off_rp_u = 0, off_rp_d = 0, off_en_u = 0, off_en_d = 0, off_lead_t = 0, off_tail_t = 0, off_diag = 0;
         size_t lds_bytes = 0;
     } lds;
     int* d_lds_csr = nullptr;
@@ -1355,16 +1355,37 @@ struct Engine : EngineBase {
         // kNN tables with k = 4 and no pads (the reference's setting): every W_u row has 4, every W_d row 5 entries -> the
         // instance with unrolled gathers that reads its rows from the global image
         lds.uniform45 = (!band && best == 8 && !lds.sb && lds.maxt == 1024 && !getenv("MGADMM_LDS_RAGGED")) ? 1 : 0;
-        for (int i = 0; i < N && lds.uniform45; ++i)
-            if (g->hWu.rowptr[i + 1] - g->hWu.rowptr[i] != 4 || g->hWd.rowptr[i + 1] - g->hWd.rowptr[i] != 5) lds.uniform45 = 0;
+        for (int i = 0; i < N && lds.uniform45; ++i) {
+            int ndiag = 0;
+            for (int e = g->hWd.rowptr[i]; e < g->hWd.rowptr[i + 1]; ++e) ndiag += g->hWd.col[e] == i;
+            if (g->hWu.rowptr[i + 1] - g->hWu.rowptr[i] != 4 || g->hWd.rowptr[i + 1] - g->hWd.rowptr[i] != 5 || ndiag != 1) lds.uniform45 = 0;
+        }
+        // diagonal entries: W_d^T[i][i] (every instance) and W_d[i][i] (uniform instances) are kept out of the tables -- inside a
+        // CG solve their operand is the thread's own vector (registers): no LDS read
+        std::vector<float> diag_d(NR, 0.f), diag_t(NR, 0.f);
+        auto strip_diag = [&](const HostCsr& h, std::vector<float>& dg) {
+            HostCsr o;
+            o.rowptr.push_back(0);
+            for (int i = 0; i < N; ++i) {
+                for (int e = h.rowptr[i]; e < h.rowptr[i + 1]; ++e) {
+                    if (h.col[e] == i) dg[i] += h.val[e];
+                    else { o.col.push_back(h.col[e]); o.val.push_back(h.val[e]); }
+                }
+                o.rowptr.push_back((int)o.col.size());
+            }
+            return o;
+        };
+        const HostCsr hWdT_off = band ? HostCsr() : strip_diag(g->hWdT, diag_t);
         // W_d^T: LDS_NLEAD leading entries per row + a tail table of 2 * tail_pairs entries per row (rows padded with
         // {own row, weight 0}): one trip count for every lane of the workgroup
         int maxlen_t = 0;
         if (!band)
-            for (int i = 0; i < N; ++i) maxlen_t = std::max(maxlen_t, g->hWdT.rowptr[i + 1] - g->hWdT.rowptr[i]);
+            for (int i = 0; i < N; ++i) maxlen_t = std::max(maxlen_t, hWdT_off.rowptr[i + 1] - hWdT_off.rowptr[i]);
         const int tp = band ? 0 : (std::max(0, maxlen_t - LDS_NLEAD) + 1) / 2;
         const int WT = LDS_NLEAD + 2 * tp;
         lds.tail_pairs = tp;
+        if (tp > 3) lds.uniform45 = 0;          // the uniform-row instances are compiled for up to three pairs of tail entries
+        const HostCsr hWd_tab = band ? HostCsr() : (lds.uniform45 ? strip_diag(g->hWd, diag_d) : g->hWd);
         // host tables with the ghosts' rows appended
         auto with_ghosts = [&](const HostCsr& h, int fixed_len) {
             HostCsr o;
@@ -1377,7 +1398,7 @@ struct Engine : EngineBase {
             return o;
         };
         const HostCsr hu = with_ghosts(g->hWu, lds.uniform45 ? 4 : 0);
-        const HostCsr hd = band ? HostCsr() : with_ghosts(g->hWd, lds.uniform45 ? 5 : 0);
+        const HostCsr hd = band ? HostCsr() : with_ghosts(hWd_tab, lds.uniform45 ? 4 : 0);
         const int nu = hu.nnz(), nd = band ? 0 : hd.nnz();
         auto al4 = [](int v) { return (v + 3) & ~3; };
         int off = 0;
@@ -1390,10 +1411,11 @@ struct Engine : EngineBase {
         off = al4(off);
         lds.off_tail_t = off; off += 2 * NR * 2 * tp + 4;     // + one pair: gather_tail requests the next pair ahead
         const int tail_ints = off - lds.off_tail_t;
+        lds.off_diag = off; off += 2 * NR;
         off += 8;                                            // the paired loops of the ragged gathers read three entries ahead
         lds.csr_ints = off;
         lds.lds_img0 = lds.uniform45 ? lds.off_tail_t : 0;
-        lds.lds_img_ints = lds.uniform45 ? tail_ints : off;
+        lds.lds_img_ints = lds.uniform45 ? tail_ints : lds.off_diag;
         // LDS row stride: T padded to an odd number of 16-byte slots (rows then start on every bank group);
         // fall back to the unpadded stride when the padded vectors do not fit
         int ts = (T + 3) / 4 * 4;
@@ -1464,10 +1486,10 @@ struct Engine : EngineBase {
             ht.rowptr.push_back(0);
             std::vector<int> from;                            // index into hWdT, -1: padding
             for (int i = 0; i < N; ++i) {
-                const int e0 = g->hWdT.rowptr[i], len = g->hWdT.rowptr[i + 1] - e0;
+                const int e0 = hWdT_off.rowptr[i], len = hWdT_off.rowptr[i + 1] - e0;
                 for (int e = 0; e < WT; ++e) {
-                    ht.col.push_back(e < len ? g->hWdT.col[e0 + e] : i);
-                    ht.val.push_back(e < len ? g->hWdT.val[e0 + e] : 0.f);
+                    ht.col.push_back(e < len ? hWdT_off.col[e0 + e] : i);
+                    ht.val.push_back(e < len ? hWdT_off.val[e0 + e] : 0.f);
                     from.push_back(e < len ? e0 + e : -1);
                 }
                 ht.rowptr.push_back((int)ht.col.size());
@@ -1482,6 +1504,8 @@ struct Engine : EngineBase {
                 }
             put_entry(lds.off_tail_t + 2 * NR * 2 * tp, 0, 0.f);
             put_entry(lds.off_tail_t + 2 * NR * 2 * tp + 2, 0, 0.f);
+            memcpy(&img[lds.off_diag], diag_d.data(), sizeof(float) * NR);
+            memcpy(&img[lds.off_diag + NR], diag_t.data(), sizeof(float) * NR);
         }
         MG_HIP(hipMalloc(&d_lds_csr, sizeof(int) * off));
         MG_HIP(hipMemcpy(d_lds_csr, img.data(), sizeof(int) * off, hipMemcpyHostToDevice));
@@ -1608,7 +1632,7 @@ struct Engine : EngineBase {
             a.cg_tol2 = p.cg_tol * p.cg_tol;
             a.csr = d_lds_csr; a.lds_img0 = lds.lds_img0; a.lds_img_ints = lds.lds_img_ints;
             a.off_rp_u = lds.off_rp_u; a.off_rp_d = lds.off_rp_d;
-            a.off_en_u = lds.off_en_u; a.off_en_d = lds.off_en_d; a.off_lead_t = lds.off_lead_t; a.off_tail_t = lds.off_tail_t;
+            a.off_en_u = lds.off_en_u; a.off_en_d = lds.off_en_d; a.off_lead_t = lds.off_lead_t; a.off_tail_t = lds.off_tail_t; a.off_diag = lds.off_diag;
             a.band_w = g->band_w;
             a.zu = zu; a.zd = zd; a.phi = phi; a.gam = gam; a.gu = gu; a.gd = gd;
             // staggered start (k_admm_lds): only when the launch runs several rounds of workgroups per CU

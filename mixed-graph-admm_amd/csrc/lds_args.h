@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 
 // entries of a W_d^T row that k_admm_lds keeps in registers during a CG solve (the rest of the row: the padded tail table)
-constexpr int LDS_NLEAD = 4;
+constexpr int LDS_NLEAD = 5;
 // most ADMM iterations one k_admm_lds launch runs (LdsArgs::J; the x pointer table has one entry more)
 constexpr int LDS_MAXJ = 16;
 
@@ -24,13 +24,14 @@ struct LdsArgsCore {
     float rho, rho_u, rho_d, mu_u, mu_d1, mu_d2;
     float cx1, cx2;        // LHS_x = HtH + cx1*I + cx2*cLdr
     double cg_tol2;        // CG_tol squared: a solve stops when r.r < CG_tol^2 (ADMM.py:360 without the square root)
-    // graph image (global), ints: [rp_u NR+1][rp_d NR+1][pad][ent_u][ent_d][lead_t NR*LDS_NLEAD][tail_t NR*2*tail_pairs][pad];
+    // graph image (global), ints: [rp_u NR+1][rp_d NR+1][pad][ent_u][ent_d][lead_t NR*LDS_NLEAD][tail_t NR*2*tail_pairs][diag 2 NR][pad];
     // entries are {LDS float offset of the neighbour's row, weight}.  The part [lds_img0, lds_img0 + lds_img_ints) is copied
     // to LDS by every workgroup (all of it, or -- instances that read the fixed-length rows from the global image once per
     // solve -- the tail table alone); off_* are offsets into the global image
     const int* csr;
     int lds_img0, lds_img_ints;
     int off_rp_u, off_rp_d, off_en_u, off_en_d, off_lead_t, off_tail_t;
+    int off_diag;          // [NR] diagonal of W_d (uniform instances: their W_d rows hold the other entries; else 0) and [NR] of W_d^T, floats
     const float* band_w;   // [T*skip] (band mode)
     // state, sample-major (B, TN)
     float *zu, *zd, *phi, *gam, *gu, *gd;

@@ -33,8 +33,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     v = dpp_step<0x112, 0xf>(v);   // row_shr:2
     v = dpp_step<0x114, 0xf>(v);   // row_shr:4
     v = dpp_step<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row total
-    v = dpp_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v = dpp_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+    // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total.  Written as the one
+    // instruction each of them is (the rows outside the row mask keep their value): through update_dpp the compiler emits a
+    // zeroing move, a v_mov_b32_dpp and an add per step.  The s_nop are the wait states a DPP operand needs after the vector
+    // instruction that wrote it (the hazard recogniser does not look into an asm statement).
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1" : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
@@ -188,9 +192,77 @@ __device__ __forceinline__ float dot(const float (&x)[TPG], const float (&y)[TPG
         return acc;
     }
 }
-// acc[k] += w * va[k]
+// y[k] = a * x[k]
 template <int TPG>
-__device__ __forceinline__ void wacc(float w, const float (&va)[TPG], float (&acc)[TPG]) { axpy<TPG>(w, va, acc); }
+__device__ __forceinline__ void scal(float a, const float (&x)[TPG], float (&y)[TPG]) {
+    if constexpr (TPG % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < TPG / 2; ++j) {
+            const f2 r = mk2(a, a) * mk2(x[2 * j], x[2 * j + 1]);
+            y[2 * j] = r.x; y[2 * j + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) y[k] = a * x[k];
+    }
+}
+// A TABLE ENTRY IN REGISTERS is the pair {LDS byte address of the 16-byte run(s) the thread gathers, weight}: the address feeds
+// ds_read_b128 as it stands, and v_pk_fma_f32 takes the weight for both halves straight from the pair (op_sel), so an
+// entry costs two registers.  (A weight splatted by hand -- mk2(w, w) -- is hoisted out of the CG loop as a second register
+// pair per entry, and the LDS addresses then went to scratch: five dependent scratch reloads per CG iteration.)
+typedef int i2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 wsplat(i2v e) {
+    const f2 f = __builtin_bit_cast(f2, e);
+    return __builtin_shufflevector(f, f, 1, 1);
+}
+// y[k] = a[k mod 2] * x[k]
+template <int TPG>
+__device__ __forceinline__ void scal2(f2 a, const float (&x)[TPG], float (&y)[TPG]) {
+    if constexpr (TPG % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < TPG / 2; ++j) {
+            const f2 r = a * mk2(x[2 * j], x[2 * j + 1]);
+            y[2 * j] = r.x; y[2 * j + 1] = r.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) y[k] = a.x * x[k];
+    }
+}
+// acc[k] += w_e * va[k]
+template <int TPG>
+__device__ __forceinline__ void wacc(i2v e, const float (&va)[TPG], float (&acc)[TPG]) {
+    if constexpr (TPG % 2 == 0) {
+        const f2 w = wsplat(e);
+#pragma unroll
+        for (int j = 0; j < TPG / 2; ++j) {
+            const f2 r = __builtin_elementwise_fma(w, mk2(va[2 * j], va[2 * j + 1]), mk2(acc[2 * j], acc[2 * j + 1]));
+            acc[2 * j] = r.x; acc[2 * j + 1] = r.y;
+        }
+    } else {
+        const float w = __int_as_float(e.y);
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) acc[k] = __builtin_fmaf(w, va[k], acc[k]);
+    }
+}
+// LDS byte address of a pointer into the dynamic LDS block, and vector access through such an address
+__device__ __forceinline__ int lds_addr(const float* p) {
+    return (int)(unsigned)(size_t)(const __attribute__((address_space(3))) float*)p;
+}
+template <int TPG>
+__device__ __forceinline__ void lds_load_a(int addr, float (&v)[TPG]) {
+    const __attribute__((address_space(3))) float* p = (const __attribute__((address_space(3))) float*)(size_t)(unsigned)addr;
+    if constexpr (TPG % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < TPG / 4; ++j) {
+            const lds_f4 q = reinterpret_cast<const __attribute__((address_space(3))) lds_f4*>(p)[j];
+            v[4 * j] = q.x; v[4 * j + 1] = q.y; v[4 * j + 2] = q.z; v[4 * j + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) v[k] = p[k];
+    }
+}
 
 // the two halves of RHS_x that do not need a neighbour, and the operand of its Ldr^T term (ADMM.py:556-564): ONE expression
 // each, used wherever the value is formed (from the state in HBM at the first trip of a launch, from the registers of the
@@ -210,129 +282,163 @@ __device__ __forceinline__ float ldrt_operand(float rho, float phi, float gam) {
 //   LDS vectors are row-major, time innermost: A[row*TS + t] (row stride TS >= T, an odd number of 16-B slots so that rows
 //   start on all banks) -> the TPG time steps of any node are one contiguous, aligned run (vector ds_read), also for a
 //   gathered neighbour; HBM state is the reference's (T, N) order per sample: element (t, i) at t*N + i (coalesced over i).
-template <int TPG, bool BAND, int NU = 0, int ND = 0>
+template <int TPG, bool BAND, int NU = 0, int ND = 0, int TP = -1>
 struct LdsCtx {
     int T, TS, N, t0, i, ig;   // i: LDS row, ig: node in HBM (ghosts: 0)
     bool active;
     float* P;
     float* Q;
-    const int2* en_u; const int2* en_d;      // entries of W_u / W_d rows (LDS image, or the global image: uniform instances)
-    const int2* lead_t;                      // W_d^T: [NR][LDS_NLEAD] leading entries (LDS or global image)
-    const int2* tail_t;                      // W_d^T: [NR][2 * tail_pairs] further entries (LDS), rows padded with {own row, 0}
+    const i2v* en_u; const i2v* en_d;        // entries {col * TS, weight} of W_u / W_d rows (LDS image, or the global image: uniform instances)
+    const i2v* lead_t;                       // W_d^T: [NR][LDS_NLEAD] leading entries (LDS or global image)
+    const i2v* tail_t;                       // W_d^T: [NR][2 * tail_pairs] further entries (LDS), rows padded with {own row, 0}
     int u0, u1, d0, d1;                      // CSR row bounds (ragged gathers)
     int tail_pairs;
+    f2 wdiag;                                // diagonal weights {W_d[i][i] (uniform instances: the table rows hold the others), W_d^T[i][i]}
     int skip, q1;
     const float* band_w;
 
-    __device__ __forceinline__ unsigned glb(int k) const { return 4u * (unsigned)((t0 + k) * N + ig); }   // HBM byte offset
+    __device__ __forceinline__ unsigned glb0() const { return 4u * (unsigned)(t0 * N + ig); }   // HBM byte offset of element k = 0 (element k: + 4 k N, added to the uniform base)
     __device__ __forceinline__ int own() const { return i * TS + t0; }            // LDS index of element k = 0
 
-    // acc[k] += sum_e w_e * IMG[col_e + t0 + k] over NE entries held in registers.  Entries carry the LDS float offset of the
-    // neighbour's row (col * TS, formed on the host); every gather of a neighbour's TPG-step window is the ALIGNED run
-    // [t0, t0+TPG-1]: conflict-free ds_read_b128 only.  The sum runs in entry order.
+    // The thread's rows of the fixed-width tables as REGISTER ENTRIES (uniform instances: requested by the kernel ahead of the
+    // phase that precedes their use; the other instances read their tables at every application and carry an unused dummy).
+    // The addresses of d and u point into the image P, those of t into Q (what the CG solves gather from); an application
+    // to another image adds the distance of the two images.
+    static constexpr bool UNI = NU > 0 && ND > 0;
+    static constexpr int NDO = ND > 0 ? ND - 1 : 0;          // entries of a uniform W_d row besides the diagonal one
+    struct Rows {
+        i2v u[NU > 0 ? NU : 1];
+        i2v d[NDO > 0 ? NDO : 1];
+        i2v t[LDS_NLEAD];
+    };
+    // table entry {col * TS, w} -> register entry for image IMG
+    __device__ __forceinline__ i2v reg_entry(i2v e, const float* IMG) const {
+        i2v r;
+        r.x = lds_addr(IMG) + 4 * (e.x + t0);
+        r.y = e.y;
+        return r;
+    }
     template <int NE>
-    __device__ __forceinline__ void gather_regs(const float* SRC, const int2 (&en)[NE], float (&acc)[TPG]) const {
-        const float* base = SRC + t0;
+    __device__ __forceinline__ void load_rows(const i2v* EN, int e0, const float* IMG, i2v (&en)[NE]) const {
+        i2v raw[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) raw[u] = EN[e0 + u];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) en[u] = reg_entry(raw[u], IMG);
+    }
+
+    // acc[k] += sum_e w_e * IMG[col_e + t0 + k] over NE register entries (`delta`: byte distance of the image read from the
+    // image the entries point into).  Every gather of a neighbour's TPG-step window is the ALIGNED run [t0, t0+TPG-1]:
+    // conflict-free ds_read_b128 only.  The sum runs in entry order.
+    template <int NE>
+    __device__ __forceinline__ void gather_regs(const i2v (&en)[NE], int delta, float (&acc)[TPG]) const {
 #pragma unroll
         for (int u = 0; u + 1 < NE; u += 2) {
             float va[TPG], vb[TPG];
-            lds_load<TPG>(base + en[u].x, va);
-            lds_load<TPG>(base + en[u + 1].x, vb);
-            const float wa = __int_as_float(en[u].y), wb = __int_as_float(en[u + 1].y);
-            wacc<TPG>(wa, va, acc);
-            wacc<TPG>(wb, vb, acc);
+            lds_load_a<TPG>(en[u].x + delta, va);
+            lds_load_a<TPG>(en[u + 1].x + delta, vb);
+            wacc<TPG>(en[u], va, acc);
+            wacc<TPG>(en[u + 1], vb, acc);
         }
         if (NE & 1) {
             float va[TPG];
-            lds_load<TPG>(base + en[NE - 1].x, va);
-            const float wa = __int_as_float(en[NE - 1].y);
-            wacc<TPG>(wa, va, acc);
+            lds_load_a<TPG>(en[NE - 1].x + delta, va);
+            wacc<TPG>(en[NE - 1], va, acc);
         }
     }
     // ragged rows of the generic instances (W_u / W_d with pads): two entries in flight per trip, per-lane trip count
-    __device__ __forceinline__ void gather(const float* SRC, const int2* EN, int e0, int e1, float (&acc)[TPG]) const {
+    __device__ __forceinline__ void gather(const float* SRC, const i2v* EN, int e0, int e1, float (&acc)[TPG]) const {
         const float* base = SRC + t0;
-        int2 na = EN[e0], nb = EN[e0 + 1];          // the arrays are padded by 3 entries: reads past e1 are safe
+        i2v na = EN[e0], nb = EN[e0 + 1];          // the arrays are padded by 3 entries: reads past e1 are safe
         int e = e0;
         for (; e + 1 < e1; e += 2) {
-            const int2 ea = na, eb = nb;
+            const i2v ea = na, eb = nb;
             float va[TPG], vb[TPG];
             lds_load<TPG>(base + ea.x, va);
             lds_load<TPG>(base + eb.x, vb);
             na = EN[e + 2];
             nb = EN[e + 3];
-            const float wa = __int_as_float(ea.y), wb = __int_as_float(eb.y);
-            wacc<TPG>(wa, va, acc);
-            wacc<TPG>(wb, vb, acc);
+            wacc<TPG>(ea, va, acc);
+            wacc<TPG>(eb, vb, acc);
         }
         if (e < e1) {
             float va[TPG];
             lds_load<TPG>(base + na.x, va);
-            const float wa = __int_as_float(na.y);
-            wacc<TPG>(wa, va, acc);
+            wacc<TPG>(na, va, acc);
         }
     }
-    // the tail of the W_d^T rows: `tail_pairs` trips for EVERY lane (workgroup-uniform count, two entries = one 16-byte read
-    // per trip); a row that ends earlier holds {own row, weight 0} there -- consecutive lanes read consecutive rows, which
-    // cannot collide.  Same instruction slots as the per-lane loop it replaces (every wave of cfg2 holds a 9- or 10-entry
-    // row), but no exec-mask bookkeeping and the next pair of entries is requested ahead.
+    // the tail of the W_d^T rows: the same number of pairs of entries for EVERY lane (two entries = one 16-byte read); a row
+    // that ends earlier holds {own row, weight 0} there -- consecutive lanes read consecutive rows, which cannot collide.
+    // Same instruction slots as the per-lane loop it replaces (every wave of cfg2 holds a 9- or 10-entry row), but no
+    // exec-mask bookkeeping, and with the pair count a compile-time constant (uniform instances) every pair is requested first.
     __device__ __forceinline__ void gather_tail(const float* SRC, float (&acc)[TPG]) const {
         const float* base = SRC + t0;
-        const lds_i4* row = static_cast<const lds_i4*>(__builtin_assume_aligned(tail_t + (size_t)i * 2 * tail_pairs, 16));
-        lds_i4 nxt = row[0];                        // (the table is padded by one pair)
-        for (int j = 0; j < tail_pairs; ++j) {
-            const lds_i4 e2 = nxt;
-            float va[TPG], vb[TPG];
-            lds_load<TPG>(base + e2.x, va);
-            lds_load<TPG>(base + e2.z, vb);
-            nxt = row[j + 1];
-            const float wa = __int_as_float(e2.y), wb = __int_as_float(e2.w);
-            wacc<TPG>(wa, va, acc);
-            wacc<TPG>(wb, vb, acc);
+        if constexpr (TP >= 0) {
+            const lds_i4* row = reinterpret_cast<const lds_i4*>(tail_t + (size_t)i * 2 * TP);
+            lds_i4 e2[TP > 0 ? TP : 1];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) e2[j] = row[j];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                float va[TPG], vb[TPG];
+                lds_load<TPG>(base + e2[j].x, va);
+                lds_load<TPG>(base + e2[j].z, vb);
+                wacc<TPG>(e2[j].xy, va, acc);
+                wacc<TPG>(e2[j].zw, vb, acc);
+            }
+        } else {
+            const lds_i4* row = reinterpret_cast<const lds_i4*>(tail_t + (size_t)i * 2 * tail_pairs);
+            lds_i4 nxt = row[0];                        // (the table is padded by one pair)
+            for (int j = 0; j < tail_pairs; ++j) {
+                const lds_i4 e2 = nxt;
+                float va[TPG], vb[TPG];
+                lds_load<TPG>(base + e2.x, va);
+                lds_load<TPG>(base + e2.z, vb);
+                nxt = row[j + 1];
+                wacc<TPG>(e2.xy, va, acc);
+                wacc<TPG>(e2.zw, vb, acc);
+            }
         }
     }
-    // entries of this thread's rows -> registers (once per solve / operator application; they do not change)
-    template <int NE>
-    __device__ __forceinline__ void load_entries(const int2* EN, int e0, int2 (&en)[NE]) const {
-#pragma unroll
-        for (int u = 0; u < NE; ++u) en[u] = EN[e0 + u];
-    }
-    __device__ __forceinline__ void load_lead(int2 (&en)[LDS_NLEAD]) const { load_entries<LDS_NLEAD>(lead_t, i * LDS_NLEAD, en); }
 
-    // acc = W_u src / W_d src / W_d^T src on the own elements (src: an LDS image), zero-initialised here
-    __device__ __forceinline__ void mul_wu(const float* SRC, float (&acc)[TPG], const int2* PRE = nullptr) const {
+    // acc = W_u src / W_d src / W_d^T src on the own elements (src: an LDS image read by that operator; own_run: the thread's
+    // OWN elements of that image -- what an entry with the thread's own row as column reads -- or nullptr: read them here).
+    // The diagonal entry of W_d^T (and of W_d in the uniform instances) is not in the tables: its weight sits in a register,
+    // and inside a CG solve its operand is the thread's own vector (lds_apply).
+    __device__ __forceinline__ void mul_wu(const float* SRC, float (&acc)[TPG], const Rows& R) const {
 #pragma unroll
         for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
-        if constexpr (NU > 0) {
-            int2 en[NU];
-            if (PRE) {
-#pragma unroll
-                for (int u = 0; u < NU; ++u) en[u] = PRE[u];
-            } else load_entries<NU>(en_u, u0, en);
-            gather_regs<NU>(SRC, en, acc);
-        } else gather(SRC, en_u, u0, u1, acc);
+        if constexpr (UNI) gather_regs<NU>(R.u, lds_addr(SRC) - lds_addr(P), acc);
+        else gather(SRC, en_u, u0, u1, acc);
     }
-    __device__ __forceinline__ void mul_wd(const float* SRC, float (&acc)[TPG], const int2* PRE = nullptr) const {
+    __device__ __forceinline__ void mul_wd(const float* SRC, float (&acc)[TPG], const Rows& R, const float* own_run = nullptr) const {
+        if constexpr (UNI) {
+            float self[TPG];
+            if (own_run) {
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
-        if constexpr (ND > 0) {
-            int2 en[ND];
-            if (PRE) {
+                for (int k = 0; k < TPG; ++k) self[k] = own_run[k];
+            } else lds_load<TPG>(SRC + own(), self);
+            scal2<TPG>(__builtin_shufflevector(wdiag, wdiag, 0, 0), self, acc);
+            gather_regs<NDO>(R.d, lds_addr(SRC) - lds_addr(P), acc);
+        } else {
 #pragma unroll
-                for (int u = 0; u < ND; ++u) en[u] = PRE[u];
-            } else load_entries<ND>(en_d, d0, en);
-            gather_regs<ND>(SRC, en, acc);
-        } else gather(SRC, en_d, d0, d1, acc);
+            for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
+            gather(SRC, en_d, d0, d1, acc);
+        }
     }
-    __device__ __forceinline__ void mul_wdt(const float* SRC, float (&acc)[TPG], const int2* PRET = nullptr) const {
+    __device__ __forceinline__ void mul_wdt(const float* SRC, float (&acc)[TPG], const Rows& R, const float* own_run = nullptr) const {
+        float self[TPG];
+        if (own_run) {
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) acc[k] = 0.f;
-        int2 en[LDS_NLEAD];
-        if (PRET) {
-#pragma unroll
-            for (int u = 0; u < LDS_NLEAD; ++u) en[u] = PRET[u];
-        } else load_lead(en);
-        gather_regs<LDS_NLEAD>(SRC, en, acc);
+            for (int k = 0; k < TPG; ++k) self[k] = own_run[k];
+        } else lds_load<TPG>(SRC + own(), self);
+        scal2<TPG>(__builtin_shufflevector(wdiag, wdiag, 1, 1), self, acc);
+        if constexpr (UNI) gather_regs<LDS_NLEAD>(R.t, lds_addr(SRC) - lds_addr(Q), acc);
+        else {
+            i2v en[LDS_NLEAD];
+            load_rows<LDS_NLEAD>(lead_t, i * LDS_NLEAD, SRC, en);
+            gather_regs<LDS_NLEAD>(en, 0, acc);
+        }
         gather_tail(SRC, acc);
     }
     // band (line-graph) stencils on the row's own time axis
@@ -363,24 +469,24 @@ struct LdsCtx {
         }
     }
     // l = Lu(src): neighbours from SRC (LDS, unshifted image), the thread's own elements of src from registers (self)  ADMM.py:138-148
-    __device__ __forceinline__ void op_lu(const float* SRC, const float (&self)[TPG], float (&l)[TPG], const int2* PRE = nullptr) const {
+    __device__ __forceinline__ void op_lu(const float* SRC, const float (&self)[TPG], float (&l)[TPG], const Rows& R) const {
         float acc[TPG];
-        mul_wu(SRC, acc, PRE);
+        mul_wu(SRC, acc, R);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = self[k] - acc[k];
     }
     // l = Ldr(src), SRC: image stored with put<-1>      ADMM.py:150-177
-    __device__ __forceinline__ void op_ldr(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
+    __device__ __forceinline__ void op_ldr(const float* SRC, const float (&self)[TPG], float (&l)[TPG], const Rows& R) const {
         float acc[TPG];
         if constexpr (BAND) band_back(SRC, acc);
-        else mul_wd(SRC, acc);
+        else mul_wd(SRC, acc, R);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((k >= 1 || t0 >= 1) ? self[k] : 0.f) - acc[k];
     }
     // l = Ldr_T(src), SRC: image stored with put<+1>    ADMM.py:179-223 (q1: identity kept on the t=0 block)
-    __device__ __forceinline__ void op_ldrt(const float* SRC, const float (&self)[TPG], float (&l)[TPG]) const {
+    __device__ __forceinline__ void op_ldrt(const float* SRC, const float (&self)[TPG], float (&l)[TPG], const Rows& R) const {
         float acc[TPG];
-        if constexpr (!BAND) mul_wdt(SRC, acc);
+        if constexpr (!BAND) mul_wdt(SRC, acc, R);
         else band_fwd(SRC, acc);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) l[k] = ((k > 0 || t0 > 0 || q1) ? self[k] : 0.f) - acc[k];
@@ -418,8 +524,9 @@ struct LdsCtx {
     // own elements -> HBM state vector (sample base already applied)
     __device__ __forceinline__ void putg(float* DST, const float (&v)[TPG]) const {
         if (active) {
+            const unsigned o0 = glb0();
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) stg(DST, glb(k), v[k]);
+            for (int k = 0; k < TPG; ++k) stg(DST + (size_t)k * N, o0, v[k]);
         }
     }
 };
@@ -458,21 +565,36 @@ __device__ __forceinline__ void slot_get(const float* S, int tid, int nthr, floa
 //   KIND 1: dc*v + c2*Ldr_T(Ldr v) ; KIND 2: dc*v + c2*Lu v ; KIND 0: dc*v
 // dc = diagonal coefficient of the own elements (H^T H or mask value, plus the rho/2 terms), see lds_diag.
 // Returns sum_k v_k * (A v)_k of the own elements.  Uses ctx.Q as scratch; contains a barrier for KIND 1.
-// Callers separate successive calls by barriers.  PRE / PRET: the thread's table rows in registers.
-template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND>
-__device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, const float (&v)[TPG], float (&av)[TPG], const float (&dc)[TPG],
-                                           float c2, const int2* PRE = nullptr, const int2* PRET = nullptr) {
+// Callers separate successive calls by barriers.  R: the thread's table rows in registers (uniform instances).
+template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND, int TP>
+__device__ __forceinline__ float lds_apply(LdsCtx<TPG, BAND, NU, ND, TP>& c, const float (&v)[TPG], float (&av)[TPG], const float (&dc)[TPG],
+                                           float c2, typename LdsCtx<TPG, BAND, NU, ND, TP>::Rows& R) {
+    // the register entries, made opaque IN PLACE once per application: their weights must be splatted INSIDE the CG loop, where
+    // the instruction selector folds the splat into the packed multiply-add (hoisted, it becomes a register pair per weight)
+    typedef LdsCtx<TPG, BAND, NU, ND, TP> Ctx;
+    if constexpr (Ctx::UNI) {
+        if (KIND == 1) {
+#pragma unroll
+            for (int u = 0; u < Ctx::NDO; ++u) MG_PIN_V(R.d[u]);
+#pragma unroll
+            for (int u = 0; u < LDS_NLEAD; ++u) MG_PIN_V(R.t[u]);
+        } else if (KIND == 2) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) MG_PIN_V(R.u[u]);
+        }
+    }
+    if (KIND == 1 && !BAND) MG_PIN_V(c.wdiag);
     float l[TPG];
 #pragma unroll
     for (int k = 0; k < TPG; ++k) l[k] = 0.f;
     if (KIND == 1) {
         if constexpr (BAND) {
             float q[TPG];
-            c.op_ldr(c.P, v, q);
+            c.op_ldr(c.P, v, q, R);
             if (SB) __syncthreads();           // single LDS vector (Q aliases P): every gather of p is done before q replaces it
             c.template put<+1>(c.Q, q);
             __syncthreads();
-            c.op_ldrt(c.Q, q, l);
+            c.op_ldrt(c.Q, q, l, R);
         } else {
             // SHIFTED OWNERSHIP of q = Ldr v.  Ldr reads time t-1 and Ldr^T time t+1, so with one partition of the time axis for
             // both vectors either the store or the gather of an image is off by one float against the 16-byte groups.  Here
@@ -487,7 +609,7 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, c
             float q[TPG];        // q[k] = (Ldr v)[t0 + k + 1]
             {
                 float acc[TPG];
-                c.mul_wd(c.P, acc, PRE);
+                c.mul_wd(c.P, acc, R, v);           // diagonal term of the uniform rows: the thread's own v (registers)
                 const bool has_next = c.t0 + TPG < c.T;
                 float vnext;
                 if constexpr (TPG % 4 == 0) vnext = static_cast<const lds_f4*>(__builtin_assume_aligned(c.P + c.own() + (has_next ? TPG : 0), 16))[0].x;
@@ -501,7 +623,7 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, c
             __syncthreads();
             {
                 float acc[TPG];
-                c.mul_wdt(c.Q, acc, PRET);
+                c.mul_wdt(c.Q, acc, R, q);          // diagonal term: position t0+k of the thread's own q row = q[k] (registers)
                 const bool has_prev = c.t0 > 0;
                 float qprev;          // q[t0]: the last value of the previous group (q[0] = 0)
                 if constexpr (TPG % 4 == 0) qprev = static_cast<const lds_f4*>(__builtin_assume_aligned(c.Q + c.own() - (has_prev ? 4 : 0), 16))[0].w;
@@ -512,7 +634,7 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, c
             }
         }
     } else if (KIND == 2) {
-        c.op_lu(c.P, v, l, PRE);
+        c.op_lu(c.P, v, l, R);
     }
     // av = dc * v (+ c2 * l);  v . av
     if constexpr (TPG % 2 == 0) {
@@ -530,11 +652,11 @@ __device__ __forceinline__ float lds_apply(const LdsCtx<TPG, BAND, NU, ND>& c, c
 }
 // diagonal coefficient d + c1 of the own elements: d = dg[el] when dg != nullptr (mask values, global
 // memory), else [hth && t < t_in]   (ADMM.py:371-379: H^T H x resp. mask * x; ADMM.py:381-399: none)
-template <int TPG, bool BAND, int NU, int ND>
-__device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND, NU, ND>& c, const float* dg, int hth, int t_in, float c1, float (&dc)[TPG]) {
+template <int TPG, bool BAND, int NU, int ND, int TP>
+__device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND, NU, ND, TP>& c, const float* dg, int hth, int t_in, float c1, float (&dc)[TPG]) {
 #pragma unroll
     for (int k = 0; k < TPG; ++k) {
-        const float d = dg ? (c.active ? ldg(dg, c.glb(k)) : 0.f) : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
+        const float d = dg ? (c.active ? ldg(dg + (size_t)k * c.N, c.glb0()) : 0.f) : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
         dc[k] = d + c1;
     }
 }
@@ -543,27 +665,19 @@ __device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND, NU, ND>& c, con
 // p in registers with a copy in LDS (ctx.P) for the neighbours' gathers, A p in registers.  x holds x0 on entry and the solution on exit.  dmask: diagonal
 // of the initial residual when a mask is given (global memory); the iterations always use [t<t_in]
 // (quirk Q2).  Returns the iteration count (k+1) or -1.  Entry requirement: no thread still reads P/Q.
-// Ghost threads enter with x = rhs = 0 and stay at 0.
-template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND>
-__device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
+// Ghost threads enter with x = rhs = 0 and stay at 0.  R: the thread's rows of the tables this solve gathers with (uniform
+// instances: W_d without its diagonal and the leading W_d^T entries for the cLdr solves, W_u for the zu solve), requested by
+// the caller ahead of the phase that precedes the solve.
+template <int TPG, bool BAND, int KIND, bool SB, int NU, int ND, int TP>
+__device__ __forceinline__ int lds_cg(LdsCtx<TPG, BAND, NU, ND, TP>& c, BlockRed& br, float (&x)[TPG], const float (&rhs)[TPG], const float* dmask,
                       int hth, int t_in, float c1, float c2, int max_cg, double tol2, float* ah, float* bh, int Bp,
-                      int* nonfinite) {
+                      int* nonfinite, typename LdsCtx<TPG, BAND, NU, ND, TP>::Rows& R) {
     float r[TPG], pv[TPG], av[TPG], dc[TPG];
-    // the thread's table rows, once per solve: W_d and the leading W_d^T entries for the cLdr solves, W_u for the zu solve
-    constexpr int NPRE = (KIND == 1 && !BAND && ND > 0) ? ND : ((KIND == 2 && NU > 0) ? NU : 0);
-    int2 pre[NPRE > 0 ? NPRE : 1];
-    if constexpr (NPRE > 0) {
-        if (KIND == 1) c.template load_entries<NPRE>(c.en_d, c.d0, pre);
-        else c.template load_entries<NPRE>(c.en_u, c.u0, pre);
-    }
-    constexpr int NPRET = (KIND == 1 && !BAND) ? LDS_NLEAD : 0;
-    int2 pret[NPRET > 0 ? NPRET : 1];
-    if constexpr (NPRET > 0) c.load_lead(pret);
     c.template put<0>(c.P, x);
     __syncthreads();
-    lds_diag<TPG, BAND, NU, ND>(c, dmask, hth, t_in, c1, dc);
-    (void)lds_apply<TPG, BAND, KIND, SB, NU, ND>(c, x, av, dc, c2, NPRE > 0 ? pre : nullptr, NPRET > 0 ? pret : nullptr);
-    if (dmask != nullptr) lds_diag<TPG, BAND, NU, ND>(c, nullptr, hth, t_in, c1, dc);     // quirk Q2: iterations use [t < t_in]
+    lds_diag<TPG, BAND, NU, ND, TP>(c, dmask, hth, t_in, c1, dc);
+    (void)lds_apply<TPG, BAND, KIND, SB, NU, ND, TP>(c, x, av, dc, c2, R);
+    if (dmask != nullptr) lds_diag<TPG, BAND, NU, ND, TP>(c, nullptr, hth, t_in, c1, dc);     // quirk Q2: iterations use [t < t_in]
 #pragma unroll
     for (int k = 0; k < TPG; ++k) {
         r[k] = rhs[k] - av[k];
@@ -572,10 +686,12 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
     float part;
     float rr = br.sumf(dot<TPG>(r, r));  // barrier: every read of P (= x0) is done
     c.template put<0>(c.P, pv);
+    // (one exit: with `break`s the compiler keeps a second copy of x for the exit paths and moves all of it once or twice per trip)
     int iters = -1;
-    for (int it = 0; it < max_cg; ++it) {
+    bool done = false;
+    for (int it = 0; it < max_cg && !done; ++it) {
         __syncthreads();                 // p complete in LDS
-        part = lds_apply<TPG, BAND, KIND, SB, NU, ND>(c, pv, av, dc, c2, NPRE > 0 ? pre : nullptr, NPRET > 0 ? pret : nullptr);
+        part = lds_apply<TPG, BAND, KIND, SB, NU, ND, TP>(c, pv, av, dc, c2, R);
         const float pAp = br.sumf(part);         // barrier: every gather from P/Q of this iteration is done
         // alpha, beta through v_rcp_f32 (1 ulp) instead of the correctly rounded division (a chain of ~10 dependent
         // instructions every thread waits for, twice per iteration: -2.9 % per launch).  The coefficients differ from
@@ -591,15 +707,12 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
             ah[(size_t)it * Bp] = alpha;
             bh[(size_t)it * Bp] = beta;
         }
-        if (!(fabsf(rrn) <= 3.0e38f)) {       // NaN / Inf: report and stop this sample
-            if (threadIdx.x == 0) *nonfinite = 1;
-            break;
-        }
-        if ((double)rrn < tol2) {        // sqrt(r.r) < CG_tol (ADMM.py:360) without the square root
-            iters = it + 1;
-            break;
-        }
-        xpby<TPG>(r, beta, pv);
+        const bool bad = !(fabsf(rrn) <= 3.0e38f);      // NaN / Inf: report and stop this sample
+        const bool conv = (double)rrn < tol2;           // sqrt(r.r) < CG_tol (ADMM.py:360) without the square root
+        if (bad && threadIdx.x == 0) *nonfinite = 1;
+        if (conv && !bad) iters = it + 1;
+        done = bad || conv;
+        xpby<TPG>(r, beta, pv);          // (also after the last iteration: a conditional update keeps two copies of p alive)
         c.template put<0>(c.P, pv);
     }
     return iters;
@@ -611,7 +724,7 @@ __device__ __forceinline__ int lds_cg(const LdsCtx<TPG, BAND, NU, ND>& c, BlockR
 // NU / ND > 0: every row of W_u / W_d holds exactly that many entries (a kNN table without pads): unrolled gathers, the
 // rows are read from the global image (L2) into registers once per solve and only the W_d^T tail table lives in LDS.
 // SLOTS: two more LDS vectors park per-thread operands across the solves (see the trip body).
-template <int TPG, bool BAND, int MAXT, bool SB, int NU = 0, int ND = 0, bool SLOTS = false>
+template <int TPG, bool BAND, int MAXT, bool SB, int NU = 0, int ND = 0, bool SLOTS = false, int TP = -1>
 __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(LdsArgs a_in) {
     constexpr bool ENTG = NU > 0 && ND > 0;       // table rows from the global image
     constexpr int NMRED = 12;                     // metric slots per wave (MGADMM_NMETRIC = 11)
@@ -690,7 +803,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     const LdsArgs& a = *kp;
 #endif
     const bool first = a.first && trip == 0;      // phi = Ldr x0 is formed by the first trip of a cold start
-    LdsCtx<TPG, BAND, NU, ND> c;
+    LdsCtx<TPG, BAND, NU, ND, TP> c;
     c.T = a.T; c.TS = a.TS; c.N = a.N;
     c.active = tid < a.nthreads;
     {
@@ -704,11 +817,44 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     c.tail_pairs = a.tail_pairs;
     {
         const int* tab = ENTG ? a.csr : img - a.lds_img0;          // where offsets into the image point
-        c.en_u = reinterpret_cast<const int2*>(tab + a.off_en_u);
-        c.en_d = reinterpret_cast<const int2*>(tab + a.off_en_d);
-        c.lead_t = reinterpret_cast<const int2*>(tab + a.off_lead_t);
-        c.tail_t = reinterpret_cast<const int2*>(img - a.lds_img0 + a.off_tail_t);
+        c.en_u = reinterpret_cast<const i2v*>(tab + a.off_en_u);
+        c.en_d = reinterpret_cast<const i2v*>(tab + a.off_en_d);
+        c.lead_t = reinterpret_cast<const i2v*>(tab + a.off_lead_t);
+        c.tail_t = reinterpret_cast<const i2v*>(img - a.lds_img0 + a.off_tail_t);
     }
+    c.wdiag = mk2(0.f, 0.f);
+    if constexpr (!BAND) {
+        const float* dg = reinterpret_cast<const float*>(a.csr + a.off_diag);      // [NR] W_d diagonal, [NR] W_d^T diagonal
+        c.wdiag = mk2(dg[c.i], dg[a.NR + c.i]);
+    }
+    // the thread's rows of the fixed-width tables (uniform instances), requested ahead of the phase that precedes their use
+    constexpr bool UNI = NU > 0 && ND > 0;
+    constexpr int NDO = ND > 0 ? ND - 1 : 0;
+    typename LdsCtx<TPG, BAND, NU, ND, TP>::Rows R;
+    // (pinned: the optimiser would otherwise re-read a table row from the global image inside the CG loop instead of keeping it)
+    auto fetch_u = [&]() {
+        if constexpr (UNI) {
+            c.template load_rows<NU>(c.en_u, c.i * NU, P, R.u);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) MG_PIN_V(R.u[u]);
+        }
+    };
+    auto fetch_d = [&]() {
+        if constexpr (UNI) {
+            c.template load_rows<NDO>(c.en_d, c.i * NDO, P, R.d);
+#pragma unroll
+            for (int u = 0; u < NDO; ++u) MG_PIN_V(R.d[u]);
+        }
+    };
+    auto fetch_t = [&]() {
+        if constexpr (UNI) {
+            c.template load_rows<LDS_NLEAD>(c.lead_t, c.i * LDS_NLEAD, Q, R.t);
+#pragma unroll
+            for (int u = 0; u < LDS_NLEAD; ++u) MG_PIN_V(R.t[u]);
+        }
+    };
+    if (first) fetch_d();
+    fetch_t();
     const size_t sb = (size_t)b * a.TN;
     const float* xo = kp->xs[trip] + sb;          // iteration k reads xs[k] and writes xs[k+1]
     float* xn = kp->xs[trip + 1] + sb;
@@ -718,27 +864,31 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     const float* yb = a.y + (size_t)b * ty * a.N;
     const bool has_phi = a.has_phi, has_zd = a.has_zd;
     const float rho = a.rho, rho_u = a.rho_u, rho_d = a.rho_d;
+    const int Nn = a.N;
 
-    // byte offsets of the own elements in a state vector, and in y (rows past its end: clamped, the value is masked)
-    unsigned off[TPG], offy[TPG];
-#pragma unroll
-    for (int k = 0; k < TPG; ++k) {
-        const int t = c.t0 + k;
-        off[k] = c.glb(k);
-        offy[k] = 4u * (unsigned)((t < ty ? t : ty - 1) * a.N + c.ig);
-    }
     // REQUEST of two operand vectors (TPG elements each per thread): 2 * TPG unconditional loads issued together and
     // waited for together; nothing crosses the fence, so the destination registers of one request are all a batch needs.
     // (an operand the ablation does not use is read through a pointer to a vector that exists, ghosts read node 0, and the
-    // values are selected afterwards: branch-free)
-    auto request2 = [&](const float* A, const float* B, const unsigned (&oa)[TPG], const unsigned (&ob)[TPG], float (&va)[TPG], float (&vb)[TPG]) {
+    // values are selected afterwards: branch-free).  Element k of a state vector: uniform base + k N floats, ONE per-thread
+    // byte offset for all of them (a register per element offset stayed alive through the whole trip: 16 VGPRs).
+    const unsigned off0 = c.glb0();
+    auto request2 = [&](const float* A, const float* B, float (&va)[TPG], float (&vb)[TPG]) {
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) { va[k] = ldg(A, oa[k]); vb[k] = ldg(B, ob[k]); }
+        for (int k = 0; k < TPG; ++k) { va[k] = ldg(A + (size_t)k * Nn, off0); vb[k] = ldg(B + (size_t)k * Nn, off0); }
         MG_REQ_FENCE();
     };
-    auto request1 = [&](const float* A, const unsigned (&oa)[TPG], float (&va)[TPG]) {
+    auto request1 = [&](const float* A, float (&va)[TPG]) {
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) va[k] = ldg(A, oa[k]);
+        for (int k = 0; k < TPG; ++k) va[k] = ldg(A + (size_t)k * Nn, off0);
+        MG_REQ_FENCE();
+    };
+    // y: rows past its end (t >= ty) are read through a clamped row index, the value is masked by the caller
+    auto request_y = [&](float (&va)[TPG]) {
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) {
+            const int t = c.t0 + k;
+            va[k] = ldg(yb, 4u * (unsigned)((t < ty ? t : ty - 1) * Nn + c.ig));
+        }
         MG_REQ_FENCE();
     };
 
@@ -750,13 +900,13 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         const float* zdp = has_zd ? zd : zu;
         const float* gdp = has_zd ? gd : gu;
         float ta[TPG], tb[TPG];
-        request2(zu, gu, off, off, ta, tb);
+        request2(zu, gu, ta, tb);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) o[k] = rhs_half(rho_u, ta[k], tb[k]);
-        request2(zdp, gdp, off, off, ta, tb);
+        request2(zdp, gdp, ta, tb);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) o[k] = has_zd ? o[k] + rhs_half(rho_d, ta[k], tb[k]) : o[k];
-        request1(yb, offy, ta);
+        request_y(ta);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) o[k] = c.active ? o[k] + ((c.t0 + k < ty) ? ta[k] : 0.f) : 0.f;
     } else {
@@ -767,10 +917,10 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         const float* gamp = use_v ? gam : gu;
         const float* phip = use_v ? phi : zu;
         float ta[TPG], tb[TPG];
-        request2(gamp, phip, off, off, ta, tb);
+        request2(gamp, phip, ta, tb);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) v[k] = (c.active && use_v) ? ldrt_operand(rho, tb[k], ta[k]) : 0.f;
-        request1(xo, off, ta);
+        request1(xo, ta);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) x[k] = c.active ? ta[k] : 0.f;
     } else {
@@ -782,7 +932,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     if constexpr (NU > 0) c.u0 = c.i * NU;
     else { c.u0 = img[a.off_rp_u - a.lds_img0 + c.i]; c.u1 = img[a.off_rp_u - a.lds_img0 + c.i + 1]; }
     if constexpr (!BAND) {
-        if constexpr (ND > 0) c.d0 = c.i * ND;
+        if constexpr (ND > 0) c.d0 = c.i * NDO;
         else { c.d0 = img[a.off_rp_d - a.lds_img0 + c.i]; c.d1 = img[a.off_rp_d - a.lds_img0 + c.i + 1]; }
     }
     BlockRed br;
@@ -799,14 +949,15 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         float ph[TPG];
         c.template put<-1>(P, x);
         __syncthreads();
-        c.op_ldr(P, x, ph);
+        c.op_ldr(P, x, ph, R);
         c.putg(phi, ph);
         float gq[TPG];
-        request1(gam, off, gq);
+        request1(gam, gq);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) v[k] = c.active ? ldrt_operand(rho, ph[k], gq[k]) : 0.f;
         __syncthreads();
     }
+    fetch_d();                // rows of the x solve
 
     // ---- RHS_x
     float rhs[TPG];
@@ -817,7 +968,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         if (has_phi) {
             c.template put<+1>(P, v);
             __syncthreads();
-            c.op_ldrt(P, v, l);
+            c.op_ldrt(P, v, l, R);
             __syncthreads();
         }
 #pragma unroll
@@ -839,28 +990,29 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         float cx1 = a.cx1, cx2 = a.cx2;
         int t_in = a.t_in;
         MG_PIN_S(cx1); MG_PIN_S(cx2); MG_PIN_S(t_in);
-        if (a.lhsx_kind == 1) itx = lds_cg<TPG, BAND, 1, SB, NU, ND>(c, br, x, rhs, mk, 1, t_in, cx1, cx2, max_cg, tol, ah, bh, Bp, nonfinite);
-        else itx = lds_cg<TPG, BAND, 0, SB, NU, ND>(c, br, x, rhs, mk, 1, t_in, cx1, 0.f, max_cg, tol, ah, bh, Bp, nonfinite);
+        if (a.lhsx_kind == 1) itx = lds_cg<TPG, BAND, 1, SB, NU, ND, TP>(c, br, x, rhs, mk, 1, t_in, cx1, cx2, max_cg, tol, ah, bh, Bp, nonfinite, R);
+        else itx = lds_cg<TPG, BAND, 0, SB, NU, ND, TP>(c, br, x, rhs, mk, 1, t_in, cx1, 0.f, max_cg, tol, ah, bh, Bp, nonfinite, R);
     }
+    fetch_u();                // rows of the zu solve
     c.putg(xn, x);
 
     // ---- x metrics, operands of the zu solve
     float z[TPG];
     {
         float xold[TPG], yv[TPG], gq[TPG];
+        request_y(yv);
         if (SLOTS) {
-            request2(yb, gu, offy, off, yv, gq);
+            request2(gu, zu, gq, z);
             slot_get<TPG>(slot0, tid, nthr, xold);
             slot_put<TPG>(slot0, tid, nthr, x);            // x_new, for the updates after the zu / zd solves
         } else {
-            request2(yb, gu, offy, off, yv, gq);
-            request1(xo, off, xold);
+            request2(gu, zu, gq, z);
+            request1(xo, xold);
         }
-        request1(zu, off, z);
         float m_xshift = 0.f, m_rec = 0.f;
         if (mk) {
             float mv[TPG];
-            request1(mk, off, mv);
+            request1(mk, mv);
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
                 const float e = c.active ? x[k] * mv[k] - yv[k] : 0.f;
@@ -894,24 +1046,26 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     {
         float c1 = rho_u * 0.5f, c2 = a.mu_u;
         MG_PIN_V(c1); MG_PIN_S(c2);
-        itzu = lds_cg<TPG, BAND, 2, SB, NU, ND>(c, br, z, rhs, nullptr, 0, 0, c1, c2, max_cg, tol, ah ? ah + hstride : nullptr,
-                                                 bh ? bh + hstride : nullptr, Bp, nonfinite);
+        itzu = lds_cg<TPG, BAND, 2, SB, NU, ND, TP>(c, br, z, rhs, nullptr, 0, 0, c1, c2, max_cg, tol, ah ? ah + hstride : nullptr,
+                                                 bh ? bh + hstride : nullptr, Bp, nonfinite, R);
     }
+    fetch_d();                // rows of the zd solve / of the Ldr of the phi prox
+    if (has_zd) fetch_t();
     float xr[TPG], zn[TPG], gn[TPG];
     {
         float zo[TPG], gv[TPG];
         // operands of the next phase (zd solve, or the phi prox)
         const float* znp = has_zd ? zd : (has_phi ? phi : zu);
         const float* gnp = has_zd ? gd : (has_phi ? gam : gu);
-        request2(znp, gnp, off, off, zn, gn);
+        request2(znp, gnp, zn, gn);
         if (SLOTS && !SB) {
             slot_get<TPG>(slot0, tid, nthr, xr);
             slot_get<TPG>(slot1, tid, nthr, gv);
             lds_load<TPG>(Q + c.own(), zo);
         } else {
-            request2(zu, gu, off, off, zo, gv);
+            request2(zu, gu, zo, gv);
             if (SLOTS) slot_get<TPG>(slot0, tid, nthr, xr);
-            else request1(xn, off, xr);
+            else request1(xn, xr);
         }
         float m_pri = 0.f, m_dual = 0.f;
         float ou[TPG];
@@ -945,14 +1099,15 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         {
             float c1 = rho_d * 0.5f, c2 = a.mu_d2;
             MG_PIN_V(c1); MG_PIN_S(c2);
-            itzd = lds_cg<TPG, BAND, 1, SB, NU, ND>(c, br, z, rhs, nullptr, 0, 0, c1, c2, max_cg, tol, ah ? ah + 2 * hstride : nullptr,
-                                                     bh ? bh + 2 * hstride : nullptr, Bp, nonfinite);
+            itzd = lds_cg<TPG, BAND, 1, SB, NU, ND, TP>(c, br, z, rhs, nullptr, 0, 0, c1, c2, max_cg, tol, ah ? ah + 2 * hstride : nullptr,
+                                                     bh ? bh + 2 * hstride : nullptr, Bp, nonfinite, R);
         }
+        fetch_u();            // rows of the Lu of the GLR term (the W_d rows stay for the Ldr of the prox)
         float zo[TPG], gv[TPG];
-        request2(zd, gd, off, off, zo, gv);
-        if (has_phi) request2(phi, gam, off, off, zn, gn);
+        request2(zd, gd, zo, gv);
+        if (has_phi) request2(phi, gam, zn, gn);
         if (SLOTS) slot_get<TPG>(slot0, tid, nthr, xr);
-        else request1(xn, off, xr);
+        else request1(xn, xr);
         float m_pri = 0.f, m_dual = 0.f;
 #pragma unroll
         for (int k = 0; k < TPG; ++k) {
@@ -970,7 +1125,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         c.putg(gd, gv);
         if (SLOTS) {                        // o of the next trip: (o_u + o_d) + H^T y
             float ou[TPG], yv[TPG];
-            request1(yb, offy, yv);
+            request_y(yv);
             slot_get<TPG>(slot1, tid, nthr, ou);
 #pragma unroll
             for (int k = 0; k < TPG; ++k) ou[k] = c.active ? (ou[k] + rhs_half(rho_d, z[k], gv[k])) + ((c.t0 + k < ty) ? yv[k] : 0.f) : 0.f;
@@ -979,9 +1134,10 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         mput(MGADMM_M_PRI_ZD, m_pri);
         mput(MGADMM_M_DUAL_ZD, m_dual);
     } else {
+        fetch_u();
         if (SLOTS) {                        // o of the next trip: o_u + H^T y
             float ou[TPG], yv[TPG];
-            request1(yb, offy, yv);
+            request_y(yv);
             slot_get<TPG>(slot1, tid, nthr, ou);
 #pragma unroll
             for (int k = 0; k < TPG; ++k) ou[k] = c.active ? ou[k] + ((c.t0 + k < ty) ? yv[k] : 0.f) : 0.f;
@@ -999,7 +1155,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     __syncthreads();
     {
         float l[TPG];
-        c.op_ldr(P, xr, l);
+        c.op_ldr(P, xr, l, R);
         const float thr = a.mu_d1 / rho;
         float pn[TPG], gnew[TPG];
 #pragma unroll
@@ -1022,7 +1178,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
             c.putg(gam, gnew);
         }
         if (!SB) {
-            c.op_lu(Q, xr, l);
+            c.op_lu(Q, xr, l, R);
 #pragma unroll
             for (int k = 0; k < TPG; ++k) m_glr += xr[k] * l[k];
         }
@@ -1032,7 +1188,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         c.template put<0>(P, xr);
         __syncthreads();
         float l[TPG];
-        c.op_lu(P, xr, l);
+        c.op_lu(P, xr, l, R);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) m_glr += xr[k] * l[k];
     }

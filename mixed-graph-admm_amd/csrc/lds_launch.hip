@@ -22,9 +22,9 @@ int allow_lds(const void* fn, int bytes) {
     return MGADMM_OK;
 }
 
-template <int TPG, bool BAND, int MAXT, bool SB, int NU = 0, int ND = 0, bool SLOTS = false>
+template <int TPG, bool BAND, int MAXT, bool SB, int NU = 0, int ND = 0, bool SLOTS = false, int TP = -1>
 int launch(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st) {
-    auto fn = k_admm_lds<TPG, BAND, MAXT, SB, NU, ND, SLOTS>;
+    auto fn = k_admm_lds<TPG, BAND, MAXT, SB, NU, ND, SLOTS, TP>;
     MG_TRY(allow_lds((const void*)fn, 160 * 1024));
     hipLaunchKernelGGL(fn, dim3(B), dim3(L.block), L.lds_bytes, st, a);
     MG_HIP(hipGetLastError());
@@ -61,8 +61,20 @@ int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st
         case 4: return launch_b<4, 1024, false>(L, a, B, st);
         case 6: return launch_b<6, 1024, false>(L, a, B, st);
         case 8:
-            if (L.uniform45 && !a.band)
-                return L.slots ? launch<8, false, 1024, false, 4, 5, true>(L, a, B, st) : launch<8, false, 1024, false, 4, 5, false>(L, a, B, st);
+            if (L.uniform45 && !a.band) {       // uniform-row instances: the pair count of the W_d^T tail table is a compile-time constant
+                switch (a.tail_pairs * 2 + (L.slots ? 1 : 0)) {
+                    case 0: return launch<8, false, 1024, false, 4, 5, false, 0>(L, a, B, st);
+                    case 1: return launch<8, false, 1024, false, 4, 5, true, 0>(L, a, B, st);
+                    case 2: return launch<8, false, 1024, false, 4, 5, false, 1>(L, a, B, st);
+                    case 3: return launch<8, false, 1024, false, 4, 5, true, 1>(L, a, B, st);
+                    case 4: return launch<8, false, 1024, false, 4, 5, false, 2>(L, a, B, st);
+                    case 5: return launch<8, false, 1024, false, 4, 5, true, 2>(L, a, B, st);
+                    case 6: return launch<8, false, 1024, false, 4, 5, false, 3>(L, a, B, st);
+                    case 7: return launch<8, false, 1024, false, 4, 5, true, 3>(L, a, B, st);
+                }
+                mg_set_error("lds: the uniform-row instances hold W_d^T rows of up to %d entries", 1 + LDS_NLEAD + 6);
+                return MGADMM_ERR_UNSUPPORTED;
+            }
             return launch_b<8, 1024, false>(L, a, B, st);
         case 12: return launch_b<12, 1024, false>(L, a, B, st);
     }
