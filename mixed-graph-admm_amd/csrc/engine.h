@@ -1340,6 +1340,18 @@ struct Engine : EngineBase {
         }
         if (!best) return MGADMM_OK;
         const bool band = g->mode == MGADMM_TEMPORAL_BAND;
+        // Twelve time steps per thread in a 640-thread workgroup (10 waves, 168 registers per thread) beat eight in a 960-thread
+        // one (15 waves, 128 registers) once the kernel stopped spilling inside the solves: cfg2 2.11 M against 2.00 M
+        // sample-iterations/s (round 3).  Taken when the graph qualifies for the uniform-row instance of that width.
+        if (!force && !band && best == 8 && T % 12 == 0 && (long)N * (T / 12) <= 640 && !getenv("MGADMM_LDS_SB") && !getenv("MGADMM_LDS_RAGGED")) {
+            bool uni = true;
+            for (int i = 0; i < N && uni; ++i) {
+                int ndiag = 0;
+                for (int e = g->hWd.rowptr[i]; e < g->hWd.rowptr[i + 1]; ++e) ndiag += g->hWd.col[e] == i;
+                uni = g->hWu.rowptr[i + 1] - g->hWu.rowptr[i] == 4 && g->hWd.rowptr[i + 1] - g->hWd.rowptr[i] == 5 && ndiag == 1;
+            }
+            if (uni) best = 12;
+        }
         const int sb_env = getenv("MGADMM_LDS_SB") ? atoi(getenv("MGADMM_LDS_SB")) : 0;   // 1: one LDS vector for p and q (experiments)
         lds.TPG = best;
         lds.G = T / best;
@@ -1354,7 +1366,7 @@ struct Engine : EngineBase {
         lds.NR = NR;
         // kNN tables with k = 4 and no pads (the reference's setting): every W_u row has 4, every W_d row 5 entries -> the
         // instance with unrolled gathers that reads its rows from the global image
-        lds.uniform45 = (!band && best == 8 && !lds.sb && lds.maxt == 1024 && !getenv("MGADMM_LDS_RAGGED")) ? 1 : 0;
+        lds.uniform45 = (!band && ((best == 8 && lds.maxt == 1024) || (best == 12 && lds.maxt == 640)) && !lds.sb && !getenv("MGADMM_LDS_RAGGED")) ? 1 : 0;
         for (int i = 0; i < N && lds.uniform45; ++i) {
             int ndiag = 0;
             for (int e = g->hWd.rowptr[i]; e < g->hWd.rowptr[i + 1]; ++e) ndiag += g->hWd.col[e] == i;

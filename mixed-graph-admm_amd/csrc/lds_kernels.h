@@ -128,10 +128,13 @@ __device__ __forceinline__ void lds_store(float* p, const float (&v)[TPG]) {
 // Global load as uniform base + 32-bit unsigned byte offset: the SGPR-base form of global_load (one offset VGPR shared by
 // every vector of a request) instead of a 64-bit address pair per access.
 __device__ __forceinline__ float ldg(const float* base, unsigned boff) {
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
+    // (explicitly global: a base that went through scalar_ptr has lost its address space, and a FLAT access has no scalar-base form)
+    const __attribute__((address_space(1))) char* g = (const __attribute__((address_space(1))) char*)base;
+    return *reinterpret_cast<const __attribute__((address_space(1))) float*>(g + boff);
 }
 __device__ __forceinline__ void stg(float* base, unsigned boff, float v) {
-    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v;
+    __attribute__((address_space(1))) char* g = (__attribute__((address_space(1))) char*)base;
+    *reinterpret_cast<__attribute__((address_space(1))) float*>(g + boff) = v;
 }
 // REQUEST fence: the loads before it are issued together and waited for together, nothing crosses it.
 #define MG_REQ_FENCE() asm volatile("" ::: "memory")
@@ -141,6 +144,14 @@ __device__ __forceinline__ void stg(float* base, unsigned boff, float v) {
 #define MG_PIN_V(x) asm volatile("" : "+v"(x))      // ... a value that was computed (no scalar float unit): stays in a vector register
 
 typedef int lds_i4 __attribute__((ext_vector_type(4)));
+// a workgroup-uniform pointer as a scalar register pair the optimiser cannot merge with a per-thread offset (readfirstlane of
+// the two halves: a plain copy when the value already sits in scalar registers)
+template <typename P>
+__device__ __forceinline__ P* scalar_ptr(P* p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (P*)(((unsigned long long)hi << 32) | lo);
+}
 // PACKED ARITHMETIC BY HAND.  This translation unit is compiled with -fno-slp-vectorize and the element loops of the CG
 // solves are written on pairs of floats (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on the register pairs (2j, 2j+1) of a
 // thread's vector): the SLP vectoriser pairs whatever looks profitable locally -- in the first branch-free build of round 3
@@ -293,6 +304,7 @@ struct LdsCtx {
     const i2v* tail_t;                       // W_d^T: [NR][2 * tail_pairs] further entries (LDS), rows padded with {own row, 0}
     int u0, u1, d0, d1;                      // CSR row bounds (ragged gathers)
     int tail_pairs;
+    unsigned kN4[TPG];                       // byte offset k * N * 4 of element k in a state vector (scalar registers, set before any divergent region)
     f2 wdiag;                                // diagonal weights {W_d[i][i] (uniform instances: the table rows hold the others), W_d^T[i][i]}
     int skip, q1;
     const float* band_w;
@@ -524,9 +536,10 @@ struct LdsCtx {
     // own elements -> HBM state vector (sample base already applied)
     __device__ __forceinline__ void putg(float* DST, const float (&v)[TPG]) const {
         if (active) {
-            const unsigned o0 = glb0();
+            unsigned o0 = glb0();
+            MG_PIN_V(o0);            // (offsets formed next to the accesses: see the kernel's request helpers)
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) stg(DST + (size_t)k * N, o0, v[k]);
+            for (int k = 0; k < TPG; ++k) stg(DST, o0 + kN4[k], v[k]);
         }
     }
 };
@@ -656,7 +669,7 @@ template <int TPG, bool BAND, int NU, int ND, int TP>
 __device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND, NU, ND, TP>& c, const float* dg, int hth, int t_in, float c1, float (&dc)[TPG]) {
 #pragma unroll
     for (int k = 0; k < TPG; ++k) {
-        const float d = dg ? (c.active ? ldg(dg + (size_t)k * c.N, c.glb0()) : 0.f) : ((hth && c.t0 + k < t_in) ? 1.f : 0.f);
+        const float d = dg ? (c.active ? ldg(dg, c.glb0() + c.kN4[k]) : 0.f) : ((hth && k < t_in - c.t0) ? 1.f : 0.f);
         dc[k] = d + c1;
     }
 }
@@ -815,6 +828,10 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     c.P = P; c.Q = Q;
     c.skip = a.skip; c.q1 = a.q1; c.band_w = a.band_w;
     c.tail_pairs = a.tail_pairs;
+    // (k N 4 in scalar registers BEFORE the first exec-masked region: a uniform value first computed inside one -- the masked
+    // stores of putg -- and used after it is kept in vector registers, and every element base after it with it)
+#pragma unroll
+    for (int k = 0; k < TPG; ++k) { c.kN4[k] = 4u * (unsigned)k * (unsigned)a.N; MG_PIN_S(c.kN4[k]); }
     {
         const int* tab = ENTG ? a.csr : img - a.lds_img0;          // where offsets into the image point
         c.en_u = reinterpret_cast<const i2v*>(tab + a.off_en_u);
@@ -871,25 +888,37 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     // (an operand the ablation does not use is read through a pointer to a vector that exists, ghosts read node 0, and the
     // values are selected afterwards: branch-free).  Element k of a state vector: uniform base + k N floats, ONE per-thread
     // byte offset for all of them (a register per element offset stayed alive through the whole trip: 16 VGPRs).
+    // Addressing: uniform vector base (scalar register pair) + a 32-bit per-thread byte offset formed NEXT TO the access
+    // (off0 + k N 4: one add) -- the scalar-base form of global_load / global_store.  An offset that is formed once and kept
+    // is widened to 64 bits in another basic block, where instruction selection no longer sees that it fits the 32-bit
+    // offset operand: every access then gets a 64-bit address in a register pair (16 VGPRs per vector, which went to scratch
+    // and were reloaded one by one in front of the loads and stores of the state).
     const unsigned off0 = c.glb0();
     auto request2 = [&](const float* A, const float* B, float (&va)[TPG], float (&vb)[TPG]) {
+        unsigned o = off0;
+        MG_PIN_V(o);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) { va[k] = ldg(A + (size_t)k * Nn, off0); vb[k] = ldg(B + (size_t)k * Nn, off0); }
+        for (int k = 0; k < TPG; ++k) { va[k] = ldg(A, o + c.kN4[k]); vb[k] = ldg(B, o + c.kN4[k]); }
         MG_REQ_FENCE();
     };
     auto request1 = [&](const float* A, float (&va)[TPG]) {
+        unsigned o = off0;
+        MG_PIN_V(o);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) va[k] = ldg(A + (size_t)k * Nn, off0);
+        for (int k = 0; k < TPG; ++k) va[k] = ldg(A, o + c.kN4[k]);
         MG_REQ_FENCE();
     };
-    // y: rows past its end (t >= ty) are read through a clamped row index, the value is masked by the caller
+    // y, masked: 0 for the rows past its end (t >= ty: read through offset 0) and for ghosts.  (Predicates on the time index are
+    // written k < limit - t0: a per-element t0 + k is formed once, kept in TPG registers for the whole trip and spilled.)
+    const int ylim = c.active ? ty - c.t0 : 0;
     auto request_y = [&](float (&va)[TPG]) {
+        unsigned o = 4u * (unsigned)(c.t0 * Nn + c.ig);
+        MG_PIN_V(o);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) {
-            const int t = c.t0 + k;
-            va[k] = ldg(yb, 4u * (unsigned)((t < ty ? t : ty - 1) * Nn + c.ig));
-        }
+        for (int k = 0; k < TPG; ++k) va[k] = ldg(yb, k < ylim ? o + c.kN4[k] : 0u);
         MG_REQ_FENCE();
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) va[k] = k < ylim ? va[k] : 0.f;
     };
 
     // ---- operands of RHS_x (ADMM.py:556-564): o = (rho_u zu - gamma_u)/2 + (rho_d zd - gamma_d)/2 + H^T y, v = gamma + rho phi
@@ -908,7 +937,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         for (int k = 0; k < TPG; ++k) o[k] = has_zd ? o[k] + rhs_half(rho_d, ta[k], tb[k]) : o[k];
         request_y(ta);
 #pragma unroll
-        for (int k = 0; k < TPG; ++k) o[k] = c.active ? o[k] + ((c.t0 + k < ty) ? ta[k] : 0.f) : 0.f;
+        for (int k = 0; k < TPG; ++k) o[k] = c.active ? o[k] + ta[k] : 0.f;
     } else {
         slot_get<TPG>(slot1, tid, nthr, o);
     }
@@ -1021,7 +1050,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         } else {
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
-                const float e = (c.active && c.t0 + k < ty) ? x[k] - yv[k] : 0.f;
+                const float e = k < ylim ? x[k] - yv[k] : 0.f;
                 m_rec += e * e;
             }
         }
@@ -1128,7 +1157,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
             request_y(yv);
             slot_get<TPG>(slot1, tid, nthr, ou);
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) ou[k] = c.active ? (ou[k] + rhs_half(rho_d, z[k], gv[k])) + ((c.t0 + k < ty) ? yv[k] : 0.f) : 0.f;
+            for (int k = 0; k < TPG; ++k) ou[k] = c.active ? (ou[k] + rhs_half(rho_d, z[k], gv[k])) + yv[k] : 0.f;
             slot_put<TPG>(slot1, tid, nthr, ou);
         }
         mput(MGADMM_M_PRI_ZD, m_pri);
@@ -1140,7 +1169,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
             request_y(yv);
             slot_get<TPG>(slot1, tid, nthr, ou);
 #pragma unroll
-            for (int k = 0; k < TPG; ++k) ou[k] = c.active ? ou[k] + ((c.t0 + k < ty) ? yv[k] : 0.f) : 0.f;
+            for (int k = 0; k < TPG; ++k) ou[k] = c.active ? ou[k] + yv[k] : 0.f;
             slot_put<TPG>(slot1, tid, nthr, ou);
         }
         mput(MGADMM_M_PRI_ZD, 0.f);

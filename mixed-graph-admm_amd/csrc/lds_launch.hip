@@ -43,8 +43,22 @@ int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st
         mg_set_error("lds: launch geometry (J %d, rows %d for %d nodes, %d of %d threads own elements)", a.J, a.NR, a.N, a.nthreads, L.block);
         return MGADMM_ERR_INVALID;
     }
-    if ((L.uniform45 && !a.band) != (L.tpg == 8 && L.uniform45 && !a.band && !L.sb && L.maxt == 1024)) {
-        mg_set_error("lds: the uniform-row instance exists for TPG 8 only");
+    if (L.uniform45 && (a.band || L.sb || !((L.tpg == 8 && L.maxt == 1024) || (L.tpg == 12 && L.maxt == 640)))) {
+        mg_set_error("lds: the uniform-row instances exist for TPG 8 (1024-thread class) and TPG 12 (640-thread class)");
+        return MGADMM_ERR_UNSUPPORTED;
+    }
+    if (L.uniform45 && L.tpg == 12) {
+        switch (a.tail_pairs * 2 + (L.slots ? 1 : 0)) {
+            case 0: return launch<12, false, 640, false, 4, 5, false, 0>(L, a, B, st);
+            case 1: return launch<12, false, 640, false, 4, 5, true, 0>(L, a, B, st);
+            case 2: return launch<12, false, 640, false, 4, 5, false, 1>(L, a, B, st);
+            case 3: return launch<12, false, 640, false, 4, 5, true, 1>(L, a, B, st);
+            case 4: return launch<12, false, 640, false, 4, 5, false, 2>(L, a, B, st);
+            case 5: return launch<12, false, 640, false, 4, 5, true, 2>(L, a, B, st);
+            case 6: return launch<12, false, 640, false, 4, 5, false, 3>(L, a, B, st);
+            case 7: return launch<12, false, 640, false, 4, 5, true, 3>(L, a, B, st);
+        }
+        mg_set_error("lds: the uniform-row instances hold W_d^T rows of up to %d entries", 1 + LDS_NLEAD + 6);
         return MGADMM_ERR_UNSUPPORTED;
     }
     if (L.sb) {
