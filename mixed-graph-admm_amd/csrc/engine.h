@@ -1340,18 +1340,9 @@ struct Engine : EngineBase {
         }
         if (!best) return MGADMM_OK;
         const bool band = g->mode == MGADMM_TEMPORAL_BAND;
-        // Twelve time steps per thread in a 640-thread workgroup (10 waves, 168 registers per thread) beat eight in a 960-thread
-        // one (15 waves, 128 registers) once the kernel stopped spilling inside the solves: cfg2 2.11 M against 2.00 M
-        // sample-iterations/s (round 3).  Taken when the graph qualifies for the uniform-row instance of that width.
-        if (!force && !band && best == 8 && T % 12 == 0 && (long)N * (T / 12) <= 640 && !getenv("MGADMM_LDS_SB") && !getenv("MGADMM_LDS_RAGGED")) {
-            bool uni = true;
-            for (int i = 0; i < N && uni; ++i) {
-                int ndiag = 0;
-                for (int e = g->hWd.rowptr[i]; e < g->hWd.rowptr[i + 1]; ++e) ndiag += g->hWd.col[e] == i;
-                uni = g->hWu.rowptr[i + 1] - g->hWu.rowptr[i] == 4 && g->hWd.rowptr[i + 1] - g->hWd.rowptr[i] == 5 && ndiag == 1;
-            }
-            if (uni) best = 12;
-        }
+        // (Twelve time steps per thread in a 640-thread workgroup -- 10 waves, 168 registers per thread, MGADMM_LDS_TPG=12 -- were
+        // 5 % ahead of eight in a 960-thread one while the eight-step instance still spilled around its solves, and are 4 %
+        // behind since it does not: cfg2 2.08 M against 2.17 M sample-iterations/s.  The smallest width stays the default.)
         const int sb_env = getenv("MGADMM_LDS_SB") ? atoi(getenv("MGADMM_LDS_SB")) : 0;   // 1: one LDS vector for p and q (experiments)
         lds.TPG = best;
         lds.G = T / best;
@@ -1591,7 +1582,6 @@ struct Engine : EngineBase {
             // (round 2 until here: seven 120 MB device copies per solve at cfg2 = 0.7 ms of a 59 ms solve).  The iterates are
             // assigned to buffers so that the one of the LAST iteration lands in x_out (an early stop on another buffer
             // costs one copy).  Outputs must not alias y / mask (mgadmm.h).
-            auto pick = [&](void* out, float* own) { return out ? static_cast<float*>(out) : own; };
             float* const xo_ = static_cast<float*>(x_out);
             // buffers for the iterates: the workspace vectors this path does not use otherwise
             static const int ring_ids[] = {V_XA, V_XB, V_ZUB, V_ZDB, V_PHIB, V_Y, V_MASK, V_R, V_P, V_Q, V_AP, V_RHS, V_TMP, V_IO0, V_IO1};
@@ -1605,28 +1595,28 @@ struct Engine : EngineBase {
                 if (k % J == 0) return vec[ring_ids[(k / J) % 3]];                          // chunk boundary
                 return vec[ring_ids[3 + ((k / J) & 1) * (J - 1) + (k % J - 1)]];           // inside chunk k / J
             };
-            float *zu = pick(state_out ? state_out->zu : nullptr, vec[V_ZUA]), *zd = pick(state_out ? state_out->zd : nullptr, vec[V_ZDA]);
-            float *phi = pick(state_out && has_phi ? state_out->phi : nullptr, vec[V_PHIA]), *gam = pick(state_out && has_phi ? state_out->gamma : nullptr, vec[V_GAM]);
-            float *gu = pick(state_out ? state_out->gamma_u : nullptr, vec[V_GU]), *gd = pick(state_out ? state_out->gamma_d : nullptr, vec[V_GD]);
-            if (state_in) {                   // warm start: the state tensors are already in this path's (B, T*N) layout
+            // zu, zd, phi and the dual variables: workspace vectors in the kernel's thread-major layout (lds_kernels.h,
+            // lds_state_index); a warm start is converted in, the exported state is converted out at the end
+            float *zu = vec[V_ZUA], *zd = vec[V_ZDA], *phi = vec[V_PHIA], *gam = vec[V_GAM], *gu = vec[V_GU], *gd = vec[V_GD];
+            if (state_in) {
                 const size_t nb = (size_t)B * TN * sizeof(float);
-                auto cp = [&](float* dst, const void* src) {
-                    return (src == nullptr || dst == src) ? hipSuccess : hipMemcpyAsync(dst, src, nb, hipMemcpyDeviceToDevice, st);
+                if (x0 != nullptr && xbuf(0) != x0) MG_HIP(hipMemcpyAsync(xbuf(0), x0, nb, hipMemcpyDeviceToDevice, st));
+                auto in = [&](float* dst, const void* src) {
+                    return src == nullptr ? (int)MGADMM_OK : mg_lds_state_layout(true, T, N, lds.TPG, B, (const float*)src, dst, st);
                 };
-                MG_HIP(cp(xbuf(0), x0));
-                MG_HIP(cp(zu, state_in->zu));
-                MG_HIP(cp(gu, state_in->gamma_u));
-                MG_HIP(cp(zd, state_in->zd));            // the vectors an ablation does not iterate on are carried through
-                MG_HIP(cp(gd, state_in->gamma_d));
-                MG_HIP(cp(phi, state_in->phi));
-                MG_HIP(cp(gam, state_in->gamma));
+                MG_TRY(in(zu, state_in->zu));
+                MG_TRY(in(gu, state_in->gamma_u));
+                MG_TRY(in(zd, state_in->zd));            // the vectors an ablation does not iterate on are carried through
+                MG_TRY(in(gd, state_in->gamma_d));
+                MG_TRY(in(phi, state_in->phi));
+                MG_TRY(in(gam, state_in->gamma));
             } else {
                 float tm = 0, t2m = 0;
                 for (int t = 0; t < p.t_in; ++t) { tm += (float)t; t2m += (float)t * (float)t; }
                 tm /= (float)p.t_in;
                 t2m /= (float)p.t_in;
                 const float den = t2m - tm * tm;
-                MG_TRY(mg_lds_init(mask != nullptr, T, p.t_in, N, B, tm, den, (const float*)y, (const float*)mask, xbuf(0), zu, zd, gam, gu, gd,
+                MG_TRY(mg_lds_init(mask != nullptr, T, p.t_in, N, lds.TPG, B, tm, den, (const float*)y, (const float*)mask, xbuf(0), zu, zd, gam, gu, gd,
                                    d_nonfinite, st));
             }
             LdsArgs a{};
@@ -1749,6 +1739,19 @@ struct Engine : EngineBase {
             float* const xc = xbuf(n_done);
             if (xc != xo_)        // early stop on the other parity
                 MG_HIP(hipMemcpyAsync(x_out, xc, (size_t)B * TN * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if (state_out) {      // the state the caller asked for, in the reference's layout
+                auto out = [&](void* dst, const float* src) {
+                    return dst == nullptr ? (int)MGADMM_OK : mg_lds_state_layout(false, T, N, lds.TPG, B, src, (float*)dst, st);
+                };
+                MG_TRY(out(state_out->zu, zu));
+                MG_TRY(out(state_out->zd, zd));
+                if (has_phi) {
+                    MG_TRY(out(state_out->phi, phi));
+                    MG_TRY(out(state_out->gamma, gam));
+                }
+                MG_TRY(out(state_out->gamma_u, gu));
+                MG_TRY(out(state_out->gamma_d, gd));
+            }
             return finish_history(hist, n_done, B, Bp, rc_final);
         }
     }

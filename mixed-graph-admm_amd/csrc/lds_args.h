@@ -65,9 +65,11 @@ struct LdsLaunch {
 
 // J ADMM iterations for B samples (one workgroup per sample); returns a mgadmm_status
 int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st);
-// initial state in sample-major layout (ADMM.py:528-544)
-int mg_lds_init(bool masked, int T, int t_in, int N, int B, float tm, float den, const float* y, const float* mask, float* x,
+// initial state (ADMM.py:528-544): x in the reference's sample-major layout, zu / zd / gamma* thread-major for time groups of TPG steps
+int mg_lds_init(bool masked, int T, int t_in, int N, int TPG, int B, float tm, float den, const float* y, const float* mask, float* x,
                 float* zu, float* zd, float* gam, float* gu, float* gd, int* nonfinite, hipStream_t st);
+// one state vector (B, T, N) <-> thread-major layout of the LDS path (lds_kernels.h, lds_state_index); src != dst
+int mg_lds_state_layout(bool to_thread_major, int T, int N, int TPG, int B, const float* src, float* dst, hipStream_t st);
 // delta_x_per_step on the sample-major layout (ADMM.py:614): scratch = double[TN * (1 + ceil(B/64))], out = double[T];
 // stop: device stop word (the kernels return at once when it is set) or nullptr
 int mg_lds_dxps(int T, int N, int B, const float* x, const float* xo, double* scratch, double* out, const int* stop, hipStream_t st);

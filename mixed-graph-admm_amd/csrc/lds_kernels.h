@@ -13,8 +13,8 @@
 //   * idle threads of the last wave are GHOSTS that own rows of zeros: one instruction stream for everybody (LdsCtx);
 //   * p.Ap and r.r are reduced with wave shuffles + a 16-entry LDS exchange in fixed order (repeatable);
 //     alpha, beta and the convergence test are computed redundantly by every thread (workgroup-uniform).
-// State (x, zu, zd, phi, gamma*) is kept in HBM in the reference's own sample-major (B, T*N) layout, so the
-// ABI tensors need no layout conversion on this path.
+// The iterates x live in HBM in the reference's own sample-major (B, T*N) layout (the ABI's x needs no conversion); zu, zd,
+// phi and the dual variables in a thread-major layout (lds_state_index), converted only when a caller asks for them.
 #pragma once
 #include "common.h"
 #include "lds_args.h"
@@ -304,6 +304,7 @@ struct LdsCtx {
     const i2v* tail_t;                       // W_d^T: [NR][2 * tail_pairs] further entries (LDS), rows padded with {own row, 0}
     int u0, u1, d0, d1;                      // CSR row bounds (ragged gathers)
     int tail_pairs;
+    unsigned so0;                            // byte offset of the thread's TPG elements in a thread-major state vector (ghosts: 0, masked)
     unsigned kN4[TPG];                       // byte offset k * N * 4 of element k in a state vector (scalar registers, set before any divergent region)
     f2 wdiag;                                // diagonal weights {W_d[i][i] (uniform instances: the table rows hold the others), W_d^T[i][i]}
     int skip, q1;
@@ -533,7 +534,26 @@ struct LdsCtx {
             if (SH > 0 && t0 + TPG == T) DST[i * TS + T - 1] = 0.f;        // time T
         }
     }
-    // own elements -> HBM state vector (sample base already applied)
+    // own elements -> thread-major state vector in HBM (sample base already applied)
+    __device__ __forceinline__ void puts(float* DST, const float (&v)[TPG]) const {
+        if (active) {
+            unsigned o = so0;
+            MG_PIN_V(o);
+            __attribute__((address_space(1))) char* g = (__attribute__((address_space(1))) char*)DST;
+            if constexpr (TPG % 4 == 0) {
+#pragma unroll
+                for (int j = 0; j < TPG / 4; ++j) {
+                    lds_f4 q;
+                    q.x = v[4 * j]; q.y = v[4 * j + 1]; q.z = v[4 * j + 2]; q.w = v[4 * j + 3];
+                    *reinterpret_cast<__attribute__((address_space(1))) lds_f4*>(g + o + 16 * j) = q;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < TPG; ++k) *reinterpret_cast<__attribute__((address_space(1))) float*>(g + o + 4 * k) = v[k];
+            }
+        }
+    }
+    // own elements -> HBM vector in the reference's (T, N) layout (sample base already applied)
     __device__ __forceinline__ void putg(float* DST, const float (&v)[TPG]) const {
         if (active) {
             unsigned o0 = glb0();
@@ -667,10 +687,19 @@ __device__ __forceinline__ float lds_apply(LdsCtx<TPG, BAND, NU, ND, TP>& c, con
 // memory), else [hth && t < t_in]   (ADMM.py:371-379: H^T H x resp. mask * x; ADMM.py:381-399: none)
 template <int TPG, bool BAND, int NU, int ND, int TP>
 __device__ __forceinline__ void lds_diag(const LdsCtx<TPG, BAND, NU, ND, TP>& c, const float* dg, int hth, int t_in, float c1, float (&dc)[TPG]) {
+    if (dg) {          // mask values: one branch-free batch of loads (ghosts read node 0, their value is dropped)
+        unsigned o = c.glb0();
+        MG_PIN_V(o);
+        float mv[TPG];
 #pragma unroll
-    for (int k = 0; k < TPG; ++k) {
-        const float d = dg ? (c.active ? ldg(dg, c.glb0() + c.kN4[k]) : 0.f) : ((hth && k < t_in - c.t0) ? 1.f : 0.f);
-        dc[k] = d + c1;
+        for (int k = 0; k < TPG; ++k) mv[k] = ldg(dg, o + c.kN4[k]);
+        MG_REQ_FENCE();
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) dc[k] = (c.active ? mv[k] : 0.f) + c1;
+    } else {
+        const int lim = hth ? t_in - c.t0 : 0;
+#pragma unroll
+        for (int k = 0; k < TPG; ++k) dc[k] = (k < lim ? 1.f : 0.f) + c1;
     }
 }
 
@@ -686,25 +715,32 @@ __device__ __forceinline__ int lds_cg(LdsCtx<TPG, BAND, NU, ND, TP>& c, BlockRed
                       int hth, int t_in, float c1, float c2, int max_cg, double tol2, float* ah, float* bh, int Bp,
                       int* nonfinite, typename LdsCtx<TPG, BAND, NU, ND, TP>::Rows& R) {
     float r[TPG], pv[TPG], av[TPG], dc[TPG];
-    c.template put<0>(c.P, x);
-    __syncthreads();
-    lds_diag<TPG, BAND, NU, ND, TP>(c, dmask, hth, t_in, c1, dc);
-    (void)lds_apply<TPG, BAND, KIND, SB, NU, ND, TP>(c, x, av, dc, c2, R);
-    if (dmask != nullptr) lds_diag<TPG, BAND, NU, ND, TP>(c, nullptr, hth, t_in, c1, dc);     // quirk Q2: iterations use [t < t_in]
+    // ONE loop, one inlined operator application: its first trip forms the initial residual (p = x0: r = rhs - A x0, then
+    // p = r), the later trips are the CG iterations.  (With the initial residual in code of its own every solve carried two
+    // copies of the operator application, and the registers of the first one were spilled around it.)
 #pragma unroll
-    for (int k = 0; k < TPG; ++k) {
-        r[k] = rhs[k] - av[k];
-        pv[k] = r[k];                    // p = r
-    }
-    float part;
-    float rr = br.sumf(dot<TPG>(r, r));  // barrier: every read of P (= x0) is done
+    for (int k = 0; k < TPG; ++k) { pv[k] = x[k]; r[k] = 0.f; }
     c.template put<0>(c.P, pv);
+    lds_diag<TPG, BAND, NU, ND, TP>(c, dmask, hth, t_in, c1, dc);
+    float rr = 0.f;
     // (one exit: with `break`s the compiler keeps a second copy of x for the exit paths and moves all of it once or twice per trip)
     int iters = -1;
-    bool done = false;
-    for (int it = 0; it < max_cg && !done; ++it) {
+    bool done = false, init = true;
+    for (int it = -1; it < max_cg && !done; ++it) {
         __syncthreads();                 // p complete in LDS
-        part = lds_apply<TPG, BAND, KIND, SB, NU, ND, TP>(c, pv, av, dc, c2, R);
+        const float part = lds_apply<TPG, BAND, KIND, SB, NU, ND, TP>(c, pv, av, dc, c2, R);
+        if (init) {                      // workgroup-uniform
+            init = false;
+            if (dmask != nullptr) lds_diag<TPG, BAND, NU, ND, TP>(c, nullptr, hth, t_in, c1, dc);     // quirk Q2: iterations use [t < t_in]
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) {
+                r[k] = rhs[k] - av[k];
+                pv[k] = r[k];            // p = r
+            }
+            rr = br.sumf(dot<TPG>(r, r));        // barrier: every read of P (= x0) and Q is done
+            c.template put<0>(c.P, pv);
+            continue;
+        }
         const float pAp = br.sumf(part);         // barrier: every gather from P/Q of this iteration is done
         // alpha, beta through v_rcp_f32 (1 ulp) instead of the correctly rounded division (a chain of ~10 dependent
         // instructions every thread waits for, twice per iteration: -2.9 % per launch).  The coefficients differ from
@@ -816,6 +852,15 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     const LdsArgs& a = *kp;
 #endif
     const bool first = a.first && trip == 0;      // phi = Ldr x0 is formed by the first trip of a cold start
+    // diagnostic build (make EXTRA=-DMGADMM_PHASE_CLOCK): the per-sample metric slots receive the 100 MHz clock at the phase
+    // boundaries of the trip instead of the metrics (tools/lds_phase_clock.py)
+#ifdef MGADMM_PHASE_CLOCK
+    unsigned long long stamps[MGADMM_NMETRIC];
+#define MG_STAMP(m) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamps[m] = wall_clock64(); } while (0)
+#else
+#define MG_STAMP(m) do { } while (0)
+#endif
+    MG_STAMP(0);
     LdsCtx<TPG, BAND, NU, ND, TP> c;
     c.T = a.T; c.TS = a.TS; c.N = a.N;
     c.active = tid < a.nthreads;
@@ -832,6 +877,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     // stores of putg -- and used after it is kept in vector registers, and every element base after it with it)
 #pragma unroll
     for (int k = 0; k < TPG; ++k) { c.kN4[k] = 4u * (unsigned)k * (unsigned)a.N; MG_PIN_S(c.kN4[k]); }
+    c.so0 = c.active ? 4u * TPG * (unsigned)tid : 0u;
     {
         const int* tab = ENTG ? a.csr : img - a.lds_img0;          // where offsets into the image point
         c.en_u = reinterpret_cast<const i2v*>(tab + a.off_en_u);
@@ -894,18 +940,36 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     // offset operand: every access then gets a 64-bit address in a register pair (16 VGPRs per vector, which went to scratch
     // and were reloaded one by one in front of the loads and stores of the state).
     const unsigned off0 = c.glb0();
-    auto request2 = [&](const float* A, const float* B, float (&va)[TPG], float (&vb)[TPG]) {
-        unsigned o = off0;
-        MG_PIN_V(o);
-#pragma unroll
-        for (int k = 0; k < TPG; ++k) { va[k] = ldg(A, o + c.kN4[k]); vb[k] = ldg(B, o + c.kN4[k]); }
-        MG_REQ_FENCE();
-    };
     auto request1 = [&](const float* A, float (&va)[TPG]) {
         unsigned o = off0;
         MG_PIN_V(o);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) va[k] = ldg(A, o + c.kN4[k]);
+        MG_REQ_FENCE();
+    };
+    // the same for the thread-major state vectors (zu, zd, phi, gamma*): TPG/4 16-byte loads per vector
+    auto load_state = [&](const float* A, float (&va)[TPG]) {
+        unsigned o = c.so0;
+        MG_PIN_V(o);
+        const __attribute__((address_space(1))) char* g = (const __attribute__((address_space(1))) char*)A;
+        if constexpr (TPG % 4 == 0) {
+#pragma unroll
+            for (int j = 0; j < TPG / 4; ++j) {
+                const lds_f4 q = *reinterpret_cast<const __attribute__((address_space(1))) lds_f4*>(g + o + 16 * j);
+                va[4 * j] = q.x; va[4 * j + 1] = q.y; va[4 * j + 2] = q.z; va[4 * j + 3] = q.w;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < TPG; ++k) va[k] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(g + o + 4 * k);
+        }
+    };
+    auto request2s = [&](const float* A, const float* B, float (&va)[TPG], float (&vb)[TPG]) {
+        load_state(A, va);
+        load_state(B, vb);
+        MG_REQ_FENCE();
+    };
+    auto request1s = [&](const float* A, float (&va)[TPG]) {
+        load_state(A, va);
         MG_REQ_FENCE();
     };
     // y, masked: 0 for the rows past its end (t >= ty: read through offset 0) and for ghosts.  (Predicates on the time index are
@@ -929,10 +993,10 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         const float* zdp = has_zd ? zd : zu;
         const float* gdp = has_zd ? gd : gu;
         float ta[TPG], tb[TPG];
-        request2(zu, gu, ta, tb);
+        request2s(zu, gu, ta, tb);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) o[k] = rhs_half(rho_u, ta[k], tb[k]);
-        request2(zdp, gdp, ta, tb);
+        request2s(zdp, gdp, ta, tb);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) o[k] = has_zd ? o[k] + rhs_half(rho_d, ta[k], tb[k]) : o[k];
         request_y(ta);
@@ -946,7 +1010,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         const float* gamp = use_v ? gam : gu;
         const float* phip = use_v ? phi : zu;
         float ta[TPG], tb[TPG];
-        request2(gamp, phip, ta, tb);
+        request2s(gamp, phip, ta, tb);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) v[k] = (c.active && use_v) ? ldrt_operand(rho, tb[k], ta[k]) : 0.f;
         request1(xo, ta);
@@ -956,6 +1020,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
 #pragma unroll
         for (int k = 0; k < TPG; ++k) { x[k] = xc[k]; v[k] = vc[k]; }
     }
+    MG_STAMP(1);
     __syncthreads();          // graph image and zeroed rows (first trip); every LDS read of the previous trip is done
     c.u0 = c.u1 = c.d0 = c.d1 = 0;
     if constexpr (NU > 0) c.u0 = c.i * NU;
@@ -979,9 +1044,9 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         c.template put<-1>(P, x);
         __syncthreads();
         c.op_ldr(P, x, ph, R);
-        c.putg(phi, ph);
+        c.puts(phi, ph);
         float gq[TPG];
-        request1(gam, gq);
+        request1s(gam, gq);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) v[k] = c.active ? ldrt_operand(rho, ph[k], gq[k]) : 0.f;
         __syncthreads();
@@ -1004,6 +1069,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         for (int k = 0; k < TPG; ++k) rhs[k] = has_phi ? l[k] * 0.5f + o[k] : o[k];
     }
     if (SLOTS) slot_put<TPG>(slot0, tid, nthr, x);         // x_old, for the x-shift metric after the solve
+    MG_STAMP(2);
     float* ah = a.record ? a.alpha_hist + b : nullptr;
     float* bh = a.record ? a.beta_hist + b : nullptr;
     int max_cg = a.max_cg;
@@ -1022,6 +1088,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         if (a.lhsx_kind == 1) itx = lds_cg<TPG, BAND, 1, SB, NU, ND, TP>(c, br, x, rhs, mk, 1, t_in, cx1, cx2, max_cg, tol, ah, bh, Bp, nonfinite, R);
         else itx = lds_cg<TPG, BAND, 0, SB, NU, ND, TP>(c, br, x, rhs, mk, 1, t_in, cx1, 0.f, max_cg, tol, ah, bh, Bp, nonfinite, R);
     }
+    MG_STAMP(3);
     fetch_u();                // rows of the zu solve
     c.putg(xn, x);
 
@@ -1031,11 +1098,11 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         float xold[TPG], yv[TPG], gq[TPG];
         request_y(yv);
         if (SLOTS) {
-            request2(gu, zu, gq, z);
+            request2s(gu, zu, gq, z);
             slot_get<TPG>(slot0, tid, nthr, xold);
             slot_put<TPG>(slot0, tid, nthr, x);            // x_new, for the updates after the zu / zd solves
         } else {
-            request2(gu, zu, gq, z);
+            request2s(gu, zu, gq, z);
             request1(xo, xold);
         }
         float m_xshift = 0.f, m_rec = 0.f;
@@ -1070,6 +1137,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         }
     }
 
+    MG_STAMP(4);
     // ---- zu solve + gamma_u update (ADMM.py:579-580, 595)
     int itzu;
     {
@@ -1078,6 +1146,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         itzu = lds_cg<TPG, BAND, 2, SB, NU, ND, TP>(c, br, z, rhs, nullptr, 0, 0, c1, c2, max_cg, tol, ah ? ah + hstride : nullptr,
                                                  bh ? bh + hstride : nullptr, Bp, nonfinite, R);
     }
+    MG_STAMP(5);
     fetch_d();                // rows of the zd solve / of the Ldr of the phi prox
     if (has_zd) fetch_t();
     float xr[TPG], zn[TPG], gn[TPG];
@@ -1086,13 +1155,13 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         // operands of the next phase (zd solve, or the phi prox)
         const float* znp = has_zd ? zd : (has_phi ? phi : zu);
         const float* gnp = has_zd ? gd : (has_phi ? gam : gu);
-        request2(znp, gnp, zn, gn);
+        request2s(znp, gnp, zn, gn);
         if (SLOTS && !SB) {
             slot_get<TPG>(slot0, tid, nthr, xr);
             slot_get<TPG>(slot1, tid, nthr, gv);
             lds_load<TPG>(Q + c.own(), zo);
         } else {
-            request2(zu, gu, zo, gv);
+            request2s(zu, gu, zo, gv);
             if (SLOTS) slot_get<TPG>(slot0, tid, nthr, xr);
             else request1(xn, xr);
         }
@@ -1111,12 +1180,13 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
             gv[k] = gv[k] + rho_u * pz;
             ou[k] = rhs_half(rho_u, z[k], gv[k]);
         }
-        c.putg(zu, z);
-        c.putg(gu, gv);
+        c.puts(zu, z);
+        c.puts(gu, gv);
         if (SLOTS) slot_put<TPG>(slot1, tid, nthr, ou);
         mput(MGADMM_M_PRI_ZU, m_pri);
         mput(MGADMM_M_DUAL_ZU, m_dual);
     }
+    MG_STAMP(6);
     // ---- zd solve + gamma_d update (ADMM.py:586-588, 597)
     int itzd = 0;
     if (has_zd) {
@@ -1131,10 +1201,11 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
             itzd = lds_cg<TPG, BAND, 1, SB, NU, ND, TP>(c, br, z, rhs, nullptr, 0, 0, c1, c2, max_cg, tol, ah ? ah + 2 * hstride : nullptr,
                                                      bh ? bh + 2 * hstride : nullptr, Bp, nonfinite, R);
         }
+        MG_STAMP(7);
         fetch_u();            // rows of the Lu of the GLR term (the W_d rows stay for the Ldr of the prox)
         float zo[TPG], gv[TPG];
-        request2(zd, gd, zo, gv);
-        if (has_phi) request2(phi, gam, zn, gn);
+        request2s(zd, gd, zo, gv);
+        if (has_phi) request2s(phi, gam, zn, gn);
         if (SLOTS) slot_get<TPG>(slot0, tid, nthr, xr);
         else request1(xn, xr);
         float m_pri = 0.f, m_dual = 0.f;
@@ -1150,8 +1221,8 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
             m_dual += dz * dz;
             gv[k] = gv[k] + rho_d * pz;
         }
-        c.putg(zd, z);
-        c.putg(gd, gv);
+        c.puts(zd, z);
+        c.puts(gd, gv);
         if (SLOTS) {                        // o of the next trip: (o_u + o_d) + H^T y
             float ou[TPG], yv[TPG];
             request_y(yv);
@@ -1176,6 +1247,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         mput(MGADMM_M_DUAL_ZD, 0.f);
     }
 
+    MG_STAMP(8);
     // ---- phi prox, gamma update, Ldr/Lu based diagnostics (ADMM.py:600-606, 619, 627-637); xr = x_new, zn = phi_old, gn = gamma
     float m_priphi = 0.f, m_dualphi = 0.f, m_dgtv = 0.f, m_dglr = 0.f, m_glr = 0.f;
     __syncthreads();          // every LDS read of the last CG is done
@@ -1203,8 +1275,8 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
             xc[k] = xr[k];                                                    // x_old of the next trip
         }
         if (has_phi) {
-            c.putg(phi, pn);
-            c.putg(gam, gnew);
+            c.puts(phi, pn);
+            c.puts(gam, gnew);
         }
         if (!SB) {
             c.op_lu(Q, xr, l, R);
@@ -1226,6 +1298,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     mput(MGADMM_M_DGTV, has_phi ? m_dgtv : 0.f);
     mput(MGADMM_M_DGLR, has_zd ? m_dglr : 0.f);
     mput(MGADMM_M_GLR, m_glr);
+    MG_STAMP(9);
     __syncthreads();          // wave totals of every metric are in LDS; the P / Q reads of this trip are done
     if (tid < MGADMM_NMETRIC) {
         // fixed association: four partial sums over the waves w = j, j+4, j+8, j+12, then (s0 + s1) + (s2 + s3)
@@ -1234,8 +1307,20 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         for (int j = 0; j < 4; ++j)
             sj[j] = (mred[j * NMRED + tid] + mred[(j + 4) * NMRED + tid]) + (mred[(j + 8) * NMRED + tid] + mred[(j + 12) * NMRED + tid]);
         double* ps = a.ps + (size_t)trip * MGADMM_NMETRIC * a.Bp;     // per-sample metric sums of this iteration
+#ifndef MGADMM_PHASE_CLOCK
         ps[(size_t)tid * a.Bp + b] = (double)((sj[0] + sj[1]) + (sj[2] + sj[3]));
+#else
+        (void)sj; (void)ps;
+#endif
     }
+#ifdef MGADMM_PHASE_CLOCK
+    MG_STAMP(10);
+    if (tid == 0) {
+        double* ps = a.ps + (size_t)trip * MGADMM_NMETRIC * a.Bp;
+        for (int m = 0; m < MGADMM_NMETRIC; ++m) ps[(size_t)m * a.Bp + b] = (double)stamps[m];
+    }
+#endif
+#undef MG_STAMP
     if (tid == 0) {
         int* const cgi = a.cg_iters + (size_t)trip * 3 * a.Bp;
         cgi[b] = itx;
@@ -1246,8 +1331,15 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
 }
 
 // initial state in sample-major layout: x0 (regression), zu = zd = x0, gamma* = 0.1   (ADMM.py:528-544)
+// element (t, i) of a sample in the THREAD-MAJOR layout of the LDS path's state vectors (zu, zd, phi, gamma*): the TPG elements
+// of thread (g, i) are contiguous, threads in thread order -- one thread reads / writes a vector as TPG/4 16-byte accesses
+// (global_load_dwordx4, lanes 48 B apart at TPG = 12) instead of TPG 4-byte ones in the reference's (T, N) order.  The 4-byte
+// form is bound by the rate at which a CU takes vector-memory instructions (64 lanes x 4 B per instruction: 38 GB/s per CU,
+// 200 such instructions per thread and ADMM iteration for the state); x, y and the mask keep the reference's layout.
+__host__ __device__ __forceinline__ int lds_state_index(int t, int i, int N, int TPG) { return ((t / TPG) * N + i) * TPG + t % TPG; }
+
 template <bool MASKED>
-__global__ __launch_bounds__(256) void k_init_lds(int T, int t_in, int N, int B, float tm, float den, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void k_init_lds(int T, int t_in, int N, int TPG, int B, float tm, float den, const float* __restrict__ y,
                                                   const float* __restrict__ mask, float* __restrict__ x, float* __restrict__ zu,
                                                   float* __restrict__ zd, float* __restrict__ gam, float* __restrict__ gu,
                                                   float* __restrict__ gd, int* __restrict__ nonfinite) {
@@ -1257,8 +1349,9 @@ __global__ __launch_bounds__(256) void k_init_lds(int T, int t_in, int N, int B,
     if (i >= N) return;
     const size_t sb = (size_t)b * T * N;
     float w, c0;
+    const float* yb = MASKED ? y + sb : y + (size_t)b * t_in * N;
+    const float* mb = MASKED ? mask + sb : nullptr;
     if (!MASKED) {
-        const float* yb = y + (size_t)b * t_in * N;
         float sy = 0.f, sty = 0.f;
         for (int t = 0; t < t_in; ++t) {
             const float v = yb[t * N + i];
@@ -1268,15 +1361,7 @@ __global__ __launch_bounds__(256) void k_init_lds(int T, int t_in, int N, int B,
         const float ym = sy / (float)t_in;
         w = (sty / (float)t_in - tm * ym) / den;
         c0 = ym - w * tm;
-        for (int t = 0; t < T; ++t) {
-            const float v = (t < t_in) ? yb[t * N + i] : w * (float)t + c0;
-            const size_t e = sb + (size_t)t * N + i;
-            x[e] = v; zu[e] = v; zd[e] = v;
-            gam[e] = 0.1f; gu[e] = 0.1f; gd[e] = 0.1f;
-        }
     } else {
-        const float* yb = y + sb;
-        const float* mb = mask + sb;
         float n = 0, ts = 0, t2s = 0, ys = 0, tys = 0;
         for (int t = 0; t < T; ++t) {
             const float m = mb[t * N + i], v = yb[t * N + i];
@@ -1290,13 +1375,49 @@ __global__ __launch_bounds__(256) void k_init_lds(int T, int t_in, int N, int B,
         w = (tymean - tmean * ymean) / dn;
         c0 = ymean - w * tmean;
         if (!(fabsf(w) <= 3.0e38f) || !(fabsf(c0) <= 3.0e38f)) *nonfinite = 1;
-        for (int t = 0; t < T; ++t) {
-            const float v = (w * (float)t + c0) * (1.f - mb[t * N + i]) + yb[t * N + i];
-            const size_t e = sb + (size_t)t * N + i;
-            x[e] = v; zu[e] = v; zd[e] = v;
-            gam[e] = 0.1f; gu[e] = 0.1f; gd[e] = 0.1f;
+    }
+    auto value = [&](int t) {
+        if (!MASKED) return (t < t_in) ? yb[t * N + i] : w * (float)t + c0;
+        return (w * (float)t + c0) * (1.f - mb[t * N + i]) + yb[t * N + i];
+    };
+    // a thread writes the TPG elements of one (time group, node) of the thread-major vectors as one contiguous run (consecutive
+    // nodes: consecutive runs), x in the reference's layout element by element (consecutive nodes: consecutive addresses)
+    for (int t0 = 0; t0 < T; t0 += TPG) {
+        const size_t es = sb + (size_t)((t0 / TPG) * N + i) * TPG;
+        if (TPG % 4 == 0) {
+            for (int k = 0; k < TPG; k += 4) {
+                lds_f4 q;
+                q.x = value(t0 + k); q.y = value(t0 + k + 1); q.z = value(t0 + k + 2); q.w = value(t0 + k + 3);
+                x[sb + (size_t)(t0 + k) * N + i] = q.x; x[sb + (size_t)(t0 + k + 1) * N + i] = q.y;
+                x[sb + (size_t)(t0 + k + 2) * N + i] = q.z; x[sb + (size_t)(t0 + k + 3) * N + i] = q.w;
+                *reinterpret_cast<lds_f4*>(zu + es + k) = q;
+                *reinterpret_cast<lds_f4*>(zd + es + k) = q;
+                lds_f4 c; c.x = c.y = c.z = c.w = 0.1f;
+                *reinterpret_cast<lds_f4*>(gam + es + k) = c;
+                *reinterpret_cast<lds_f4*>(gu + es + k) = c;
+                *reinterpret_cast<lds_f4*>(gd + es + k) = c;
+            }
+        } else {
+            for (int k = 0; k < TPG; ++k) {
+                const float v = value(t0 + k);
+                x[sb + (size_t)(t0 + k) * N + i] = v;
+                zu[es + k] = v; zd[es + k] = v;
+                gam[es + k] = 0.1f; gu[es + k] = 0.1f; gd[es + k] = 0.1f;
+            }
         }
     }
+}
+
+// a state vector between the reference's (B, T, N) layout and the thread-major layout (warm start in, exported state out)
+template <bool TO_THREAD_MAJOR>
+__global__ __launch_bounds__(256) void k_state_layout(int T, int N, int TPG, const float* __restrict__ src, float* __restrict__ dst) {
+    const int e = blockIdx.x * 256 + threadIdx.x;        // index in the reference layout
+    if (e >= T * N) return;
+    const size_t sb = (size_t)blockIdx.y * T * N;
+    const int t = e / N, i = e - t * N;
+    const int es = lds_state_index(t, i, N, TPG);
+    if (TO_THREAD_MAJOR) dst[sb + es] = src[sb + e];
+    else dst[sb + e] = src[sb + es];
 }
 
 // delta_x_per_step on the sample-major layout.  Pass 1: workgroup (e-block, b-slice) sums x - x_old over

@@ -96,11 +96,19 @@ int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st
     return MGADMM_ERR_UNSUPPORTED;
 }
 
-int mg_lds_init(bool masked, int T, int t_in, int N, int B, float tm, float den, const float* y, const float* mask, float* x,
+int mg_lds_init(bool masked, int T, int t_in, int N, int TPG, int B, float tm, float den, const float* y, const float* mask, float* x,
                 float* zu, float* zd, float* gam, float* gu, float* gd, int* nonfinite, hipStream_t st) {
     dim3 grid((N + 255) / 256, B);
-    if (masked) hipLaunchKernelGGL((k_init_lds<true>), grid, dim3(256), 0, st, T, t_in, N, B, tm, den, y, mask, x, zu, zd, gam, gu, gd, nonfinite);
-    else hipLaunchKernelGGL((k_init_lds<false>), grid, dim3(256), 0, st, T, t_in, N, B, tm, den, y, (const float*)nullptr, x, zu, zd, gam, gu, gd, nonfinite);
+    if (masked) hipLaunchKernelGGL((k_init_lds<true>), grid, dim3(256), 0, st, T, t_in, N, TPG, B, tm, den, y, mask, x, zu, zd, gam, gu, gd, nonfinite);
+    else hipLaunchKernelGGL((k_init_lds<false>), grid, dim3(256), 0, st, T, t_in, N, TPG, B, tm, den, y, (const float*)nullptr, x, zu, zd, gam, gu, gd, nonfinite);
+    MG_HIP(hipGetLastError());
+    return MGADMM_OK;
+}
+
+int mg_lds_state_layout(bool to_thread_major, int T, int N, int TPG, int B, const float* src, float* dst, hipStream_t st) {
+    dim3 grid((T * N + 255) / 256, B);
+    if (to_thread_major) hipLaunchKernelGGL((k_state_layout<true>), grid, dim3(256), 0, st, T, N, TPG, src, dst);
+    else hipLaunchKernelGGL((k_state_layout<false>), grid, dim3(256), 0, st, T, N, TPG, src, dst);
     MG_HIP(hipGetLastError());
     return MGADMM_OK;
 }

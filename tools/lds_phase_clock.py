@@ -4,7 +4,7 @@ Needs a diagnostic build of the library in which the per-sample metric slots rec
 boundaries instead of the metrics:
 
     make -C mixed-graph-admm_amd/csrc OUT=$PWD/ko/lib_clock.so OBJDIR=$PWD/ko/build_clock EXTRA=-DMGADMM_PHASE_CLOCK
-    MGADMM_LIB=ko/lib_clock.so python tools/lds_phase_clock.py
+    MGADMM_LIB=$PWD/ko/lib_clock.so python tools/lds_phase_clock.py [iterations]      (MGADMM_LDS_CHUNK, MGADMM_LDS_TPG as usual)
 
 Prints, per ADMM iteration, the mean over the samples of every phase in microseconds and the share of the workgroup's
 lifetime, plus the gap between the end of one workgroup and the start of the next one on the same CU slot (estimated
@@ -20,20 +20,17 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import bench  # noqa: E402
 
-NAMES = ["CSR image -> LDS", "batch 1 + RHS_x", "x solve", "store x, batch 2, metrics", "zu solve", "batch 3, duals, metrics",
-         "zd solve", "batch 4, duals, metrics", "phi prox + Ldr / Lu diagnostics", "5 metric reductions"]
+NAMES = ["operands of RHS_x (HBM at the first trip of a launch, registers / LDS slot later)", "RHS_x (first trip of a cold start: + phi = Ldr x0)",
+         "x solve", "store x, x metrics, operands of the zu solve", "zu solve", "zu / gamma_u update, operands of the zd solve",
+         "zd solve", "zd / gamma_d update, operands of the prox", "phi prox + Ldr / Lu diagnostics", "metric totals"]
 
 
 def _mean(v):
     return float(torch.as_tensor(v).double().mean())
 
 
-NAMES_RHS = ["CSR image -> LDS", None, "x solve", "store x, batch 2, metrics", "zu solve", "batch 3, duals, metrics", "zd solve"]
-
-
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    rhs_mode = len(sys.argv) > 2 and sys.argv[2] == "rhs"     # library built with -DMGADMM_PHASE_CLOCK=2
     dev = torch.device("cuda:0")
     n, B, cl, dl, info, _ = bench.build_problem("cfg2")
     B = int(os.environ.get("CLOCK_B", B))
@@ -47,22 +44,13 @@ def main():
     m = np.asarray(blk.metrics_per_sample)    # [iters][11][B]  clock ticks of 10 ns
     for it in range(m.shape[0]):
         t = m[it] * 0.01                      # microseconds
-        if len(sys.argv) > 2 and sys.argv[2] == "flat":           # -DMGADMM_PHASE_CLOCK=3
-            print(f"ADMM iteration {it}: flat request of the batch-1 operands {np.mean(t[8] - t[1]):.2f} us, the kernel's own batch 1 "
-                  f"afterwards (L2-hot) {np.mean(t[9] - t[8]):.2f} us, RHS_x {np.mean(t[2] - t[9]):.2f} us")
-            continue
-        if rhs_mode:
-            print(f"ADMM iteration {it}: batch 1 requests {np.mean(t[8] - t[0]):.2f} us, CSR image -> LDS {np.mean(t[1] - t[8]):.2f} us, "
-                  f"put + barrier {np.mean(t[9] - t[1]):.2f} us, Ldr^T gather + barrier {np.mean(t[10] - t[9]):.2f} us, "
-                  f"to the x solve {np.mean(t[2] - t[10]):.2f} us; workgroup lifetime {np.mean(t[7] - t[0]):.1f} us up to the end of the zd solve")
-            continue
         d = np.diff(t, axis=0)                # [10][B]
         life = t[10] - t[0]
         print(f"ADMM iteration {it}: workgroup lifetime mean {life.mean():.1f} us (min {life.min():.1f}, max {life.max():.1f}); "
               f"launch span {t[10].max() - t[0].min():.1f} us; CG iterations x/zu/zd "
               f"{_mean(blk.CG_iter_x[it]):.2f} / {_mean(blk.CG_iter_zu[it]):.2f} / {_mean(blk.CG_iter_zd[it]):.2f}")
         for k, nm in enumerate(NAMES):
-            print(f"    {nm:36s} {d[k].mean():8.2f} us  {100 * d[k].mean() / life.mean():5.1f} %")
+            print(f"    {nm:88s} {d[k].mean():8.2f} us  {100 * d[k].mean() / life.mean():5.1f} %")
         # hand-over gap: k-th earliest end vs (256 + k)-th earliest start (one workgroup per CU, 256 CUs)
         st, en = np.sort(t[0]), np.sort(t[10])
         ncu = 256
