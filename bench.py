@@ -21,14 +21,16 @@ Metric: ADMM sample-iterations per second = (samples over all ranks) * K / secon
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of the timed workload, measured live with
 HIP events recorded around every launch on the launch stream during the timed solve:
   * cfg2 (LDS-resident path): k_admm_lds never streams its vectors from HBM, so it is priced against the LDS:
-    `bound` = "lds", `achieved` = LDS bytes the kernel's gathers / stores move per launch (exact count from the CSR
-    row lengths, the time-group width and the CG iteration counts of the timed solve) / average launch duration,
-    `peak` = 150 TB/s (MI355X_MICROARCH.md: aggregate ds_read_b128 rate); `traffic` = HBM bytes per launch from the
-    rocprofv3 PMC passes, `hbm_achieved` = traffic / duration.
+    `bound` = "lds", `achieved` = LDS bytes the kernel's gathers / stores move per launch (exact count from the table
+    widths, the time-group width and the CG iteration counts of the timed solve; a launch runs several ADMM iterations:
+    `iterations_per_launch`) / average launch duration, `peak` = 150 TB/s (MI355X_MICROARCH.md: aggregate ds_read_b128
+    rate); `traffic` = HBM bytes per launch from the rocprofv3 PMC passes (profiles/traffic.json holds them per ADMM
+    iteration), `hbm_achieved` = traffic / duration.
   * cfg3 / cfg4 (streaming path): the sparse-Laplacian SpMM inside the CG solves against the HBM roofline
     (`bound` = "hbm", 8 TB/s), algorithmic bytes per launch as accumulated by the library.
 The default (cfg2) run also measures the cfg3 SpMM roofline -- the configuration the >= 60 % target is quoted on -- over
-5 ADMM iterations (> 200 live launches); its figures are flattened into the same `roofline` object as `cfg3_spmm_*`.
+6 ADMM iterations (> 200 live launches); its figures are flattened into the same `roofline` object as `cfg3_spmm_*`, and a
+2-iteration leg on the 100k-node graph of cfg4 (B = 256, the per-GPU slice) is reported as `roofline_cfg4`.
 `cpu_baseline` is the CPU oracle (NumPy/SciPy restatement of the reference) on a bounded sample of the same windows:
 one worker process per host core (at most 16, the GPU box's CPU share), each solving its windows one at a time
 (B = 1: the reference's semantics), plus the vectorised-batch rate of one core and the full cfg1 run.
@@ -210,27 +212,34 @@ def load_traffic(workload):
 
 
 def lds_bytes_per_launch(blk, B, cg, T=24):
-    """LDS bytes one k_admm_lds launch (= one ADMM iteration of B samples) moves, counted from what the kernel issues
-    (csrc/lds_kernels.h): per CSR entry and time group one entry read (8 B) + ceil(TPG/4) aligned 16-B row reads (the
-    images gathered by the time-shifted operators are stored shifted: no edge reads); per operator application one 4-B
-    store per element.  Operator applications: x / zd solves (K+1) x (Ldr + Ldr^T), zu solve (K+1) x Lu, + RHS_x (Ldr^T),
-    phi prox (Ldr) and GLR (Lu).  K = measured mean CG iterations of the timed solve."""
+    """LDS bytes ONE ADMM iteration of B samples moves in k_admm_lds, counted from what the kernel's element-owning threads
+    issue (csrc/lds_kernels.h, round-3 form).  run = 4 TPG bytes = the aligned window of a gathered row.
+      cLdr application inside a CG solve: W_d entries x run + 16 (v of the next time group) ; (lead + 2 tail_pairs) W_d^T
+        positions x run (the padded tail positions are read like real ones) + 16 tail_pairs (the tail table entries) + 16 ;
+        stores of q and p: 2 run.  Uniform instances keep the diagonal entries and the table rows in registers: W_d has
+        ND - 1 gathered entries, no entry reads; the other instances read 8 B per table entry.
+      Lu application: W_u entries x run (+ 8 B per entry: generic instances) + the store of p.
+      Per iteration besides the solves: RHS_x (one W_d^T application on an image + its own-row read + the image store),
+        phi prox (W_d) and GLR (W_u).
+    Operator applications: x / zd solves K + 1 each, zu solve K + 1.  K = measured mean CG iterations of the timed solve."""
     from mgadmm import _lib
     h = blk._solvers[(1, torch.float32)][0]
-    tpg = _lib.query(h, _lib.Q_LDS_TPG)
-    G = T // tpg
-    nu, nd, nt = (_lib.query(h, q) for q in (_lib.Q_NNZ_U, _lib.Q_NNZ_D, _lib.Q_NNZ_DT))
-    run = ((tpg + 3) // 4) * 16 if tpg % 4 == 0 else tpg * 4
-    edge = 0          # round 2: shifted LDS images (LdsCtx::put<SH>), the edge element comes with the aligned run
-    per_lu = G * nu * (8 + run)
-    per_ldr = G * nd * (8 + run + edge)
-    per_ldrt = G * nt * (8 + run + edge)
-    TN = T * blk.n_nodes
-    store = TN * 4
+    q = lambda w: _lib.query(h, w)
+    tpg, nt = q(_lib.Q_LDS_TPG), q(_lib.Q_LDS_THREADS)
+    uni, tp, lead = q(_lib.Q_LDS_UNIFORM), q(_lib.Q_LDS_TAIL_PAIRS), q(_lib.Q_LDS_LEAD)
+    n = blk.n_nodes
+    nu, nd = q(_lib.Q_NNZ_U) / n, q(_lib.Q_NNZ_D) / n          # entries per row
+    run = 4 * tpg
+    edge = 16 if tpg % 4 == 0 else 4
+    ent = 0 if uni else 8                                      # table entry reads per gathered entry
+    wd = ((nd - 1) if uni else nd) * (run + ent) + edge
+    wdt = (lead + 2 * tp) * run + (0 if uni else lead * 8) + 2 * tp * 8 + edge
+    wu = nu * (run + ent)
+    cldr = wd + wdt + 2 * run
+    lu = wu + run
     kx, kzu, kzd = cg["CG_iter_x"], cg["CG_iter_zu"], cg["CG_iter_zd"]
-    per_sample = ((kx + 1) + (kzd + 1)) * (per_ldr + per_ldrt + 2 * store) + (kzu + 1) * (per_lu + store) \
-        + (per_ldrt + store) + (per_ldr + store) + per_lu
-    return B * per_sample, tpg
+    per_thread = ((kx + 1) + (kzd + 1)) * cldr + (kzu + 1) * lu + (wdt + 2 * run) + (wd + 2 * run) + (wu + run)
+    return B * nt * per_thread, tpg
 
 
 def roofline_from_prof(prof, workload, path="stream", blk=None, B=0, cg=None, steps=0):
@@ -259,8 +268,8 @@ def roofline_from_prof(prof, workload, path="stream", blk=None, B=0, cg=None, st
         return out
     bytes_per = p0["bytes"] / p0["count"]
     ach = bytes_per / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "sparse mixed-graph Laplacian SpMM inside CG (k_tile / k_rows, batch-innermost; LDS-tiled on "
-                                      "cluster-ordered graphs)",
+    return {"bound": "hbm", "kernel": "sparse mixed-graph Laplacian SpMM inside CG: k_cldr (fused Ldr^T Ldr with the CG vector update folded "
+                                      "into its loads: x / zd solves) and k_tile (Lu: zu solve), batch-innermost, LDS-tiled",
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "launches": p0["count"], "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": bytes_per,
             "cg_update_kernel_GBs": (prof[1]["bytes"] / max(prof[1]["ms"], 1e-9) / 1e6) if prof[1]["count"] else None}
@@ -274,10 +283,11 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-cfg3-leg", action="store_true")
+    ap.add_argument("--no-cfg3-leg", action="store_true", help="skip the streaming-path legs (cfg3 and cfg4)")
+    ap.add_argument("--no-cfg4-leg", action="store_true", help="skip the 100k-node leg only")
     ap.add_argument("--no-prof", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
-    ap.add_argument("--gather-chunks", type=int, default=0,
+    ap.add_argument("--gather-chunks", type=int, default=1,
                     help="N > 1: sub-blocks per rank; the final gather of one overlaps the solve of the next "
                          "(default 1: two half-batch solves cost 3.7 %% more than one at cfg2 -- 1.585 vs 1.646 M "
                          "sample-iterations/s, fixed per-solve work -- which is more than the overlap hides of a 120 MB/rank "
@@ -319,9 +329,10 @@ def main():
     # iterates, mgadmm.dist.sharded_solve(chunks=) does the same); the gather of sub-block c is issued asynchronously
     # (RCCL runs it on its own stream) and overlaps the solve of sub-block c+1, so only the last sub-block's share of the
     # exchange is exposed.  N = 1 has no exchange and solves its block in one piece.  Default: one piece everywhere.
-    chunks = args.gather_chunks or 1
-    chunks = max(1, min(chunks, B)) if world > 1 else 1
-    Bc = (B + chunks - 1) // chunks
+    from mgadmm.dist import shard_bounds
+    chunks = max(1, min(args.gather_chunks, B)) if world > 1 else 1
+    blocks = [bd for bd in (shard_bounds(B, chunks, c) for c in range(chunks)) if bd[1] > bd[0]]     # non-empty sub-blocks
+    Bc = max(b - a for a, b in blocks)
 
     def run(iters, prof):
         blk.max_ADMM_iter = iters
@@ -331,12 +342,11 @@ def main():
         if world == 1:
             return blk.combined_loop(y, print_info=False), None
         pending, x = [], None
-        for c in range(chunks):             # the only exchange of the path: final gather of the x shards (RCCL/xGMI)
-            a, b = c * Bc, min(B, (c + 1) * Bc)
+        for c, (a, b) in enumerate(blocks):  # the only exchange of the path: final gather of the x shards (RCCL/xGMI)
             x = blk.combined_loop(y[a:b], print_info=False)
             xs = x.to(cdev)
             gathered = [torch.empty_like(xs) for _ in range(world)] if rank == 0 else None
-            work = dist.gather(xs, gathered, dst=0, async_op=c + 1 < chunks)
+            work = dist.gather(xs, gathered, dst=0, async_op=c + 1 < len(blocks))
             pending.append((xs, gathered, work))      # the buffers stay referenced until the exchange has completed
         for _, _, work in pending:
             if work is not None:
@@ -386,37 +396,49 @@ def main():
                        "event_readback_ms_after_timed_region": round(prof_read_ms, 3)},
         }
         out["config"]["mean_cg_iters_x_zu_zd"] = [round(cg_counts[k2], 2) for k2 in ("CG_iter_x", "CG_iter_zu", "CG_iter_zd")]
-        out["roofline"] = roofline_from_prof(prof, args.workload, path, blk=blk, B=Bc, cg=cg_counts, steps=args.steps * chunks) if prof else None
+        out["roofline"] = roofline_from_prof(prof, args.workload, path, blk=blk, B=Bc, cg=cg_counts, steps=args.steps * len(blocks)) if prof else None
 
-    # ---- CG-SpMV roofline leg on the 10k-node graph (BASELINE config 3), rank 0 of a 1-GPU run only
-    if rank == 0 and world == 1 and args.workload == "cfg2" and not args.no_cfg3_leg:
-        blk.close()
-        del x
-        torch.cuda.empty_cache()
-        n3, B3, cl3, dl3, info3, desc3 = build_problem("cfg3")
+    # ---- CG-SpMV roofline legs on the streaming path, rank 0 of a 1-GPU run only: cfg3 (10k-node graph, BASELINE config 3:
+    # the configuration the >= 60 % target is quoted on) and a short cfg4 leg (100k-node graph, the per-GPU slice of BASELINE
+    # config 4) so that a driver-timed number exists for the largest graph
+    def streaming_leg(name, iters):
+        n3, B3, cl3, dl3, info3, desc3 = build_problem(name)
         b3 = make_solver(n3, cl3, dl3, info3, device)
         y3 = synth_y(n3, B3, 12, seed=1, offset=0, device=device)
         b3.max_ADMM_iter = 1
         b3.combined_loop(y3, print_info=False)
         torch.cuda.synchronize()
-        it3 = 5                                   # > 200 live SpMM-in-CG launches
-        b3.max_ADMM_iter = it3
+        b3.max_ADMM_iter = iters
         b3._reset_history()
         b3.prof_begin()
         t0 = time.perf_counter()
         b3.combined_loop(y3, print_info=False)
         torch.cuda.synchronize()
         dt3 = time.perf_counter() - t0
-        r3 = roofline_from_prof(b3.prof_end(), "cfg3")
+        r3 = roofline_from_prof(b3.prof_end(), name)
         if r3:
-            r3["config"] = f"cfg3: {desc3}, B={B3}, fp32, {it3} ADMM iterations"
-            r3["sample_iterations_per_s"] = B3 * it3 / dt3
-            if out.get("roofline"):
-                for k3 in ("bound", "achieved", "peak", "frac", "traffic", "launches", "avg_launch_us",
-                           "algorithmic_bytes_per_launch", "cg_update_kernel_GBs", "sample_iterations_per_s"):
-                    out["roofline"]["cfg3_spmm_" + k3] = r3[k3]
-        out["roofline_cfg3"] = r3
+            r3["config"] = f"{name}: {desc3}, B={B3}, fp32, {iters} ADMM iterations"
+            r3["sample_iterations_per_s"] = B3 * iters / dt3
         b3.close()
+        del b3, y3
+        torch.cuda.empty_cache()
+        return r3
+
+    if rank == 0 and world == 1 and args.workload == "cfg2" and not args.no_cfg3_leg:
+        blk.close()
+        del x
+        torch.cuda.empty_cache()
+        r3 = streaming_leg("cfg3", 6)             # 6 ADMM iterations: > 200 live SpMM-in-CG launches
+        if r3 and out.get("roofline"):
+            for k3 in ("bound", "achieved", "peak", "frac", "traffic", "launches", "avg_launch_us",
+                       "algorithmic_bytes_per_launch", "cg_update_kernel_GBs", "sample_iterations_per_s"):
+                out["roofline"]["cfg3_spmm_" + k3] = r3[k3]
+        out["roofline_cfg3"] = r3
+        if not args.no_cfg4_leg:
+            try:
+                out["roofline_cfg4"] = streaming_leg("cfg4", 2)
+            except Exception as e:  # noqa: BLE001  (52 GB workspace: never lose the line to it)
+                out["roofline_cfg4"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

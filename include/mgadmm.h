@@ -135,6 +135,9 @@ typedef struct {
 typedef struct mgadmm_graph mgadmm_graph;
 typedef struct mgadmm_solver mgadmm_solver;
 
+/* "mgadmm <major>.<minor>.<patch> (gfx950)".  The minor number changes whenever a struct of this header grows (0.2:
+ * mgadmm_params gained cg_convergence and max_inner_iter): a caller built against an older header must be rebuilt --
+ * compare the string before passing structs. */
 const char* mgadmm_version(void);
 const char* mgadmm_last_error(void);
 
@@ -168,7 +171,13 @@ typedef enum {
     MGADMM_Q_NNZ_U = 5,         /* stored entries of W_u, W_d, W_d^T                                                */
     MGADMM_Q_NNZ_D = 6,
     MGADMM_Q_NNZ_DT = 7,
-    MGADMM_Q_TILE_ROWS = 8      /* node rows per LDS tile of the streaming SpMM kernel (0: plain row kernel)        */
+    MGADMM_Q_TILE_ROWS = 8,     /* node rows per LDS tile of the streaming SpMM kernel (0: plain row kernel)        */
+    MGADMM_Q_LDS_UNIFORM = 9,   /* 1: k_admm_lds instance with fixed-width table rows held in registers             */
+    MGADMM_Q_LDS_TAIL_PAIRS = 10,/* pairs of W_d^T entries per row in the padded tail table of k_admm_lds            */
+    MGADMM_Q_LDS_LEAD = 11,     /* leading W_d^T entries per row (held in registers / read first)                  */
+    MGADMM_Q_LDS_SLOTS = 12,    /* 1: two LDS vectors park per-thread operands across the solves                    */
+    MGADMM_Q_LDS_CHUNK = 13,    /* ADMM iterations per k_admm_lds launch when the iteration count is fixed          */
+    MGADMM_Q_LDS_ROWS = 14      /* LDS rows of an image: nodes + ghost rows                                         */
 } mgadmm_query_t;
 int mgadmm_solver_query(const mgadmm_solver* s, int32_t what, int64_t* out);
 

@@ -13,6 +13,10 @@ int mgadmm_solver_create(mgadmm_graph* g, const mgadmm_params* p, int32_t max_ba
     MG_REQUIRE(p->max_cg_iter >= 1 && p->max_admm_iter >= 1, "solver_create: iteration limits must be >= 1");
     MG_REQUIRE(p->cg_convergence == MGADMM_CG_PER_SAMPLE || p->cg_convergence == MGADMM_CG_BATCH_MAX,
                "solver_create: cg_convergence should be per_sample (0) or batch_max (1), got %d", p->cg_convergence);
+    if (p->path == MGADMM_PATH_LDS && p->cg_convergence == MGADMM_CG_BATCH_MAX) {
+        mg_set_error("solver_create: the LDS-resident path implements per-sample CG convergence only (batch_max: streaming path)");
+        return MGADMM_ERR_UNSUPPORTED;
+    }
     mgadmm_solver* s = new mgadmm_solver();
     s->g = g;
     s->p = *p;

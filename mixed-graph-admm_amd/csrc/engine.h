@@ -479,6 +479,13 @@ struct Engine : EngineBase {
         MG_REQUIRE(np.t_in >= 1 && np.t_in <= T, "set_params: t_in out of range");
         MG_REQUIRE(np.max_cg_iter >= 1 && np.max_admm_iter >= 1, "set_params: iteration limits must be >= 1");
         MG_REQUIRE(np.ablation >= 0 && np.ablation <= 3, "set_params: bad ablation");
+        MG_REQUIRE(np.cg_convergence == MGADMM_CG_PER_SAMPLE || np.cg_convergence == MGADMM_CG_BATCH_MAX,
+                   "set_params: cg_convergence should be per_sample (0) or batch_max (1), got %d", np.cg_convergence);
+        MG_REQUIRE(np.max_inner_iter >= 0, "set_params: max_inner_iter must be >= 0 (got %d)", np.max_inner_iter);
+        if (np.path == MGADMM_PATH_LDS && np.cg_convergence == MGADMM_CG_BATCH_MAX) {
+            mg_set_error("set_params: the LDS-resident path implements per-sample CG convergence only (batch_max: streaming path)");
+            return MGADMM_ERR_UNSUPPORTED;
+        }
         p = np;
         sv->p = np;
         MG_HIP(hipSetDevice(g->device));
@@ -496,6 +503,12 @@ struct Engine : EngineBase {
             case MGADMM_Q_LDS_THREADS: *out = lds.nthreads; break;
             case MGADMM_Q_LDS_BYTES: *out = (int64_t)lds.lds_bytes; break;
             case MGADMM_Q_LDS_ROW_STRIDE: *out = lds.TS; break;
+            case MGADMM_Q_LDS_UNIFORM: *out = lds.uniform45; break;
+            case MGADMM_Q_LDS_TAIL_PAIRS: *out = lds.tail_pairs; break;
+            case MGADMM_Q_LDS_LEAD: *out = LDS_NLEAD; break;
+            case MGADMM_Q_LDS_SLOTS: *out = lds.slots; break;
+            case MGADMM_Q_LDS_CHUNK: *out = std::max(1, std::min(lds_chunk, LDS_MAXJ_POOL)); break;
+            case MGADMM_Q_LDS_ROWS: *out = lds.NR; break;
             case MGADMM_Q_NNZ_U: *out = g->hWu.nnz(); break;
             case MGADMM_Q_NNZ_D: *out = g->hWd.nnz(); break;
             case MGADMM_Q_NNZ_DT: *out = g->hWdT.nnz(); break;
@@ -1224,16 +1237,26 @@ struct Engine : EngineBase {
         const int n_outer = p.max_admm_iter, n_inner = p.max_inner_iter;
         const size_t rows_needed = (size_t)n_outer * n_inner;
         if (rows_needed > (size_t)max_admm_alloc) {          // d_cg_iters holds one row of 3 x Bp counts per inner iteration
-            if (d_cg_iters) MG_HIP(hipFree(d_cg_iters));
-            d_cg_iters = nullptr;
-            MG_HIP(hipMalloc(&d_cg_iters, sizeof(int) * rows_needed * 3 * Bp_max));
-            // d_hist / d_dxps keep their size: they are indexed by ADMM iteration < p.max_admm_iter <= rows_needed
+            // the three history buffers grow together (max_admm_alloc is their common row count); the new ones are all
+            // allocated before an old one is released, so a failed allocation leaves the solver as it was
+            int* nc = nullptr;
             double *nh = nullptr, *nd = nullptr;
-            MG_HIP(hipMalloc(&nh, sizeof(double) * rows_needed * MGADMM_NMETRIC));
-            MG_HIP(hipMalloc(&nd, sizeof(double) * rows_needed * T));
+            const hipError_t e1 = hipMalloc(&nc, sizeof(int) * rows_needed * 3 * Bp_max);
+            const hipError_t e2 = e1 == hipSuccess ? hipMalloc(&nh, sizeof(double) * rows_needed * MGADMM_NMETRIC) : e1;
+            const hipError_t e3 = e2 == hipSuccess ? hipMalloc(&nd, sizeof(double) * rows_needed * T) : e2;
+            if (e3 != hipSuccess) {
+                if (nc) (void)hipFree(nc);
+                if (nh) (void)hipFree(nh);
+                if (nd) (void)hipFree(nd);
+                (void)hipGetLastError();
+                mg_set_error("two_loops: cannot allocate the CG-count history of %zu inner iterations x %d samples (%s)", rows_needed,
+                             Bp_max, hipGetErrorString(e3));
+                return MGADMM_ERR_NOMEM;
+            }
+            if (d_cg_iters) (void)hipFree(d_cg_iters);
             if (d_hist) (void)hipFree(d_hist);
             if (d_dxps) (void)hipFree(d_dxps);
-            d_hist = nh; d_dxps = nd;
+            d_cg_iters = nc; d_hist = nh; d_dxps = nd;
             max_admm_alloc = (int)rows_needed;
         }
         MG_HIP(hipMemsetAsync(d_nonfinite, 0, sizeof(int), st));

@@ -20,7 +20,8 @@ void mg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* mgadmm_last_error(void) { return g_err; }
-extern "C" const char* mgadmm_version(void) { return "mgadmm 0.1.0 (gfx950)"; }
+// 0.2: mgadmm_params gained cg_convergence, max_inner_iter; 0.3: round-3 LDS path, more mgadmm_query_t codes (no struct change)
+extern "C" const char* mgadmm_version(void) { return "mgadmm 0.3.0 (gfx950)"; }
 
 int mg_transpose_csr(const HostCsr& A, HostCsr& At) {
     const int n = A.n, nnz = A.nnz();

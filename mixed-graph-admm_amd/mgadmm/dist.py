@@ -57,9 +57,11 @@ def sharded_solve(solve_fn, y, mask=None, *, gather="root", group=None, chunks=1
     """Run ``solve_fn(y_shard, mask_shard) -> x_shard`` on this rank's batch block and collect the shards.
 
     ``solve_fn`` is normally ``ADMM_algorithm.combined_loop`` bound to a solver on this rank's GPU.
-      gather="root" (or True)  one gather to rank ``dst`` (the exchange BASELINE.json's north star names): rank ``dst``
-                               returns the full (B,T,N,C) tensor, every other rank returns None;
-      gather="all"             all_gather: every rank returns the full tensor (costs world_size x the memory);
+      gather="root"            one gather to rank ``dst`` (the exchange BASELINE.json's north star names): rank ``dst``
+                               returns the full (B,T,N,C) tensor, every other rank returns None (the default since
+                               round 2; round 1 returned the full tensor everywhere);
+      gather="all" (or True)   all_gather: every rank returns the full tensor (costs world_size x the memory) -- what
+                               ``gather=True`` has always meant;
       gather=False             no exchange, each rank returns its own block.
     Works without an initialised process group (world_size 1).
 
@@ -70,7 +72,7 @@ def sharded_solve(solve_fn, y, mask=None, *, gather="root", group=None, chunks=1
     for early stopping).
     """
     if gather is True:
-        gather = "root"
+        gather = "all"
     if gather not in ("root", "all", False):
         raise ValueError(f"gather must be 'root', 'all' or False, got {gather!r}")
     ws, rk = _world(group)
@@ -138,7 +140,13 @@ def _as_matrix(v):
     return t
 
 
-def gather_history(history, n_local, *, group=None, dst=0):
+def _last_rows(m, rows):
+    """The last `rows` rows of a history matrix (a list that survives ``init_iterations`` -- recover_list -- is longer than
+    the others: the rows of the solve just finished are its last ones)."""
+    return m[m.shape[0] - rows:] if m.shape[0] >= rows else m
+
+
+def gather_history(history, n_local, *, group=None, dst=0, chunks=1):
     """Whole-batch residual history of a sharded solve, re-formed on rank ``dst`` from the per-shard histories
     (SURVEY.md 8e): norms combine as sqrt(sum_shards local^2) (ADMM.py:612-636 are Frobenius norms over the batch
     tensor), regularisers (means over samples, ADMM.py:230-246) as sample-weighted means.  One gather of a few hundred
@@ -148,23 +156,52 @@ def gather_history(history, n_local, *, group=None, dst=0):
     Ranks may have executed different iteration counts (early stop is per shard): the combined lists cover the
     iterations EVERY non-empty shard executed; ``iters_per_shard`` holds each shard's own count.  ``delta_x_per_step`` is
     the norm of a batch MEAN (ADMM.py:614) and cannot be combined from shard norms: it is returned per shard.
+    Only the rows of the LAST solve of every list enter (a list may hold older rows: ``recover_list`` survives
+    ``init_iterations`` like in the reference); every list travels with its own row count.
+    ``chunks``: the value given to ``sharded_solve(chunks=)`` -- the rank's history then holds one block of rows per
+    sub-block (all with the same iteration count: use a fixed ``max_ADMM_iter``); the blocks are combined like shards
+    before the exchange, ``delta_x_per_step_per_shard`` keeps one block per sub-block.
     Returns a dict on rank ``dst`` and None elsewhere.
     """
     get = (lambda k: history[k]) if isinstance(history, dict) else (lambda k: getattr(history, k))
     ws, rk = _world(group)
+    chunks = max(1, int(chunks))
     mats = {k: _as_matrix(get(k)) for k in _NORM_KEYS + _MEAN_KEYS}
     dxps = torch.stack([torch.as_tensor(v, dtype=torch.float64) for v in get("delta_x_per_step")]) \
         if len(get("delta_x_per_step")) else torch.zeros((0, 0), dtype=torch.float64)
-    iters = mats["p_res_list"].shape[0]
+    rows = mats["p_res_list"].shape[0]
+    if chunks > 1 and n_local > 0:
+        nblk = sum(1 for c in range(chunks) if shard_bounds(n_local, chunks, c)[1] > shard_bounds(n_local, chunks, c)[0])
+        if nblk == 0 or rows % nblk:
+            raise ValueError(f"gather_history(chunks={chunks}): {rows} history rows are not {nblk} blocks of equal length "
+                             "(sub-blocks must run the same iteration count: check_stop=False)")
+        iters = rows // nblk
+        sizes_c = [shard_bounds(n_local, chunks, c)[1] - shard_bounds(n_local, chunks, c)[0] for c in range(chunks)]
+        sizes_c = [v for v in sizes_c if v > 0]
+        for k in mats:
+            m = _last_rows(mats[k], rows)
+            blocks = [m[j * iters:(j + 1) * iters] for j in range(nblk)]
+            if k in _NORM_KEYS:
+                mats[k] = torch.sqrt(sum(b ** 2 for b in blocks))
+            else:
+                mats[k] = sum(b * n for b, n in zip(blocks, sizes_c)) / float(n_local)
+    else:
+        iters = rows
+        mats = {k: _last_rows(mats[k], iters) for k in mats}
+    dxps = _last_rows(dxps, rows)
     if ws == 1:
         out = {k: mats[k] for k in mats}
         out.update(iters_per_shard=[iters], samples_per_shard=[n_local], delta_x_per_step_per_shard=[dxps])
         return out
     dev = _coll_device(group)
-    # fixed-size packet per rank: [n_local, iters, ncol per key..., payload padded to the longest]
-    cols = [mats[k].shape[1] if mats[k].numel() else 0 for k in mats] + [dxps.shape[1] if dxps.numel() else 0]
-    head = torch.tensor([n_local, iters] + cols, dtype=torch.float64)
-    body = torch.cat([mats[k].reshape(-1) for k in mats] + [dxps.reshape(-1)])
+    # fixed-size packet per rank: [n_local, iters, (rows, cols) per key ..., payload padded to the longest]
+    keys = list(mats) + ["delta_x_per_step"]
+    vals = [mats[k] for k in mats] + [dxps]
+    shape = []
+    for v in vals:
+        shape += [v.shape[0], v.shape[1] if v.numel() else 0]
+    head = torch.tensor([n_local, iters] + shape, dtype=torch.float64)
+    body = torch.cat([v.reshape(-1) for v in vals])
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
     dist.all_gather(sizes, torch.tensor([head.numel() + body.numel()], dtype=torch.int64, device=dev), group=group)
     width = int(max(int(s) for s in sizes))
@@ -175,17 +212,16 @@ def gather_history(history, n_local, *, group=None, dst=0):
     dist.gather(pkt, parts, dst=gdst, group=group)
     if rk != dst:
         return None
-    keys = list(mats)
     shards = []
     for p in parts:
         p = p.cpu()
         nl, it = int(p[0]), int(p[1])
-        cs = [int(v) for v in p[2:2 + len(keys) + 1]]
-        off = 2 + len(keys) + 1
+        off = 2 + 2 * len(keys)
         d = {}
-        for k, c in zip(keys + ["delta_x_per_step"], cs):
-            d[k] = p[off: off + it * c].reshape(it, c) if c else torch.zeros((it, 0), dtype=torch.float64)
-            off += it * c
+        for j, k in enumerate(keys):
+            r, c = int(p[2 + 2 * j]), int(p[3 + 2 * j])
+            d[k] = p[off: off + r * c].reshape(r, c) if c else torch.zeros((r, 0), dtype=torch.float64)
+            off += r * c
         shards.append((nl, it, d))
     live = [s for s in shards if s[0] > 0]
     n_it = min(s[1] for s in live) if live else 0

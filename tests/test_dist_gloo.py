@@ -38,6 +38,9 @@ def _worker(rank, world, port, B, out_dir):
         return torch.from_numpy(o.combined_loop(ys.numpy()))
 
     x = sharded_solve(solve_fn, y, gather="all")
+    assert torch.equal(sharded_solve(solve_fn, y, gather=True), x)          # True has always meant: everywhere
+    calls.clear()
+    sharded_solve(solve_fn, y, gather="all")
     lo, hi = shard_bounds(B, world, rank)
     assert calls == ([hi - lo] if hi > lo else [])
     # the per-shard residual history, combined on rank 0: sqrt(sum local^2) / sample-weighted means
@@ -47,6 +50,37 @@ def _worker(rank, world, port, B, out_dir):
     if rank == 0:
         np.savez(os.path.join(out_dir, "hist.npz"), **{k: np.asarray(v) for k, v in gh.items() if k.endswith("_list")},
                  iters=np.array(gh["iters_per_shard"]), samples=np.array(gh["samples_per_shard"]))
+    # a list that survived an earlier solve (recover_list is kept by init_iterations, ADMM.py:100-133) is longer than the
+    # others: only its last rows belong to this solve, and every list travels with its own row count
+    class _H:
+        pass
+    hx = _H()
+    for k in ("p_res_list", "d_res_list", "x_shift_list", "GLR_list", "DGTV_list", "DGLR_list", "delta_x_per_step"):
+        setattr(hx, k, getattr(hist, k))
+    hx.recover_list = [123.0, 456.0] + list(hist.recover_list)
+    gx = gather_history(hx, hi - lo)
+    if rank == 0:
+        for k in gh:
+            if k.endswith("_list"):
+                assert torch.equal(torch.as_tensor(gx[k]), torch.as_tensor(gh[k])), k
+    # sub-blocks (sharded_solve(chunks=)): the rank's history holds one block of rows per sub-block; combined like shards
+    per_call = []
+
+    def solve_keep(ys, ms):
+        o = make_oracle(meta, "knn")
+        o.max_ADMM_iter = 3
+        per_call.append(o)
+        return torch.from_numpy(o.combined_loop(ys.numpy()))
+
+    sharded_solve(solve_keep, y, gather=False, chunks=2)
+    hc = _H()
+    for k in ("p_res_list", "d_res_list", "x_shift_list", "recover_list", "GLR_list", "DGTV_list", "DGLR_list", "delta_x_per_step"):
+        setattr(hc, k, [row for o in per_call for row in getattr(o.hist, k)] if per_call else getattr(hist, k))
+    gc = gather_history(hc, hi - lo, chunks=2)
+    if rank == 0:
+        for k in gh:
+            if k.endswith("_list"):
+                np.testing.assert_allclose(np.asarray(gc[k]), np.asarray(gh[k]), rtol=1e-10, err_msg=k)
     # default: ONE gather to rank 0 -- only rank 0 holds the full tensor
     xr = sharded_solve(solve_fn, y)
     assert (xr is not None) == (rank == 0)

@@ -18,9 +18,9 @@ def short(n):
     m = re.search(r'(k_rows|k_tile)<(\w+), (\d+), (\w+)(?:<[^>]*>)?, (\d+)', n)
     if m:
         return f"{m.group(1)}<{m.group(4)},GW{m.group(5)}{',Fold' if 'TileSrcFold' in n else ''}>"
-    m = re.search(r'k_admm_lds<(\d+), (\w+)', n)
+    m = re.search(r'k_admm_lds<(\d+), (\w+), (\d+), (\w+), (\d+), (\d+), (\w+), (-?\d+)>', n)
     if m:
-        return f"k_admm_lds<{m.group(1)},{m.group(2)}>"
+        return f"k_admm_lds<TPG{m.group(1)},{'uniform' if m.group(5) != '0' else 'ragged'}>"
     return n.split('(')[0][:40]
 
 
