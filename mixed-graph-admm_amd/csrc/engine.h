@@ -1354,12 +1354,21 @@ struct Engine : EngineBase {
         const int tpgs[] = {1, 2, 3, 4, 6, 8, 12};
         int best = 0;
         const char* force = getenv("MGADMM_LDS_TPG");      // tests / experiments: force one time-group width
+        // does the graph qualify for the uniform-row instances (TPG 8 and 12: table rows in registers, branch-free solves)?
+        bool uni_graph = g->mode != MGADMM_TEMPORAL_BAND && !getenv("MGADMM_LDS_SB") && !getenv("MGADMM_LDS_RAGGED");
+        for (int i = 0; i < N && uni_graph; ++i) {
+            int ndiag = 0;
+            for (int e = g->hWd.rowptr[i]; e < g->hWd.rowptr[i + 1]; ++e) ndiag += g->hWd.col[e] == i;
+            uni_graph = g->hWu.rowptr[i + 1] - g->hWu.rowptr[i] == 4 && g->hWd.rowptr[i + 1] - g->hWd.rowptr[i] == 5 && ndiag == 1;
+        }
         for (int tpg : tpgs) {
             if (T % tpg) continue;
             const int G = T / tpg;
             if ((long)N * G > 1024) continue;
             if (force && atoi(force) != tpg) continue;
-            if (!best) best = tpg;        // smallest TPG = most threads
+            if (!best) best = tpg;        // smallest TPG = most threads ...
+            if (uni_graph && !force && tpg == 8) best = 8;      // ... unless the uniform-row instance of width 8 applies: it is the
+                                                                 // fastest form also for graphs small enough for narrower groups
         }
         if (!best) return MGADMM_OK;
         const bool band = g->mode == MGADMM_TEMPORAL_BAND;
@@ -1380,7 +1389,7 @@ struct Engine : EngineBase {
         lds.NR = NR;
         // kNN tables with k = 4 and no pads (the reference's setting): every W_u row has 4, every W_d row 5 entries -> the
         // instance with unrolled gathers that reads its rows from the global image
-        lds.uniform45 = (!band && ((best == 8 && lds.maxt == 1024) || (best == 12 && lds.maxt == 640)) && !lds.sb && !getenv("MGADMM_LDS_RAGGED")) ? 1 : 0;
+        lds.uniform45 = (!band && (best == 8 || best == 12) && !lds.sb && !getenv("MGADMM_LDS_RAGGED")) ? 1 : 0;
         for (int i = 0; i < N && lds.uniform45; ++i) {
             int ndiag = 0;
             for (int e = g->hWd.rowptr[i]; e < g->hWd.rowptr[i + 1]; ++e) ndiag += g->hWd.col[e] == i;
@@ -1410,7 +1419,6 @@ struct Engine : EngineBase {
         const int tp = band ? 0 : (std::max(0, maxlen_t - LDS_NLEAD) + 1) / 2;
         const int WT = LDS_NLEAD + 2 * tp;
         lds.tail_pairs = tp;
-        if (tp > 3) lds.uniform45 = 0;          // the uniform-row instances are compiled for up to three pairs of tail entries
         const HostCsr hWd_tab = band ? HostCsr() : (lds.uniform45 ? strip_diag(g->hWd, diag_d) : g->hWd);
         // host tables with the ghosts' rows appended
         auto with_ghosts = [&](const HostCsr& h, int fixed_len) {

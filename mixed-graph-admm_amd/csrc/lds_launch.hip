@@ -43,9 +43,19 @@ int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st
         mg_set_error("lds: launch geometry (J %d, rows %d for %d nodes, %d of %d threads own elements)", a.J, a.NR, a.N, a.nthreads, L.block);
         return MGADMM_ERR_INVALID;
     }
-    if (L.uniform45 && (a.band || L.sb || !((L.tpg == 8 && L.maxt == 1024) || (L.tpg == 12 && L.maxt == 640)))) {
-        mg_set_error("lds: the uniform-row instances exist for TPG 8 (1024-thread class) and TPG 12 (640-thread class)");
+    if (L.uniform45 && (a.band || L.sb || !((L.tpg == 8 && L.maxt == 1024) || L.tpg == 12))) {
+        mg_set_error("lds: the uniform-row instances exist for TPG 8 (1024-thread class) and TPG 12");
         return MGADMM_ERR_UNSUPPORTED;
+    }
+    if (L.uniform45 && L.tpg == 12 && L.maxt == 1024) {        // 342 .. 512 nodes: two time groups in a workgroup of up to 1024 threads (no room for slots)
+        if (L.slots) { mg_set_error("lds: no slot instance in the 1024-thread class of TPG 12"); return MGADMM_ERR_UNSUPPORTED; }
+        switch (a.tail_pairs) {
+            case 0: return launch<12, false, 1024, false, 4, 5, false, 0>(L, a, B, st);
+            case 1: return launch<12, false, 1024, false, 4, 5, false, 1>(L, a, B, st);
+            case 2: return launch<12, false, 1024, false, 4, 5, false, 2>(L, a, B, st);
+            case 3: return launch<12, false, 1024, false, 4, 5, false, 3>(L, a, B, st);
+        }
+        return launch<12, false, 1024, false, 4, 5, false, -1>(L, a, B, st);        // longer tails: pair count at run time
     }
     if (L.uniform45 && L.tpg == 12) {
         switch (a.tail_pairs * 2 + (L.slots ? 1 : 0)) {
@@ -58,8 +68,7 @@ int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st
             case 6: return launch<12, false, 640, false, 4, 5, false, 3>(L, a, B, st);
             case 7: return launch<12, false, 640, false, 4, 5, true, 3>(L, a, B, st);
         }
-        mg_set_error("lds: the uniform-row instances hold W_d^T rows of up to %d entries", 1 + LDS_NLEAD + 6);
-        return MGADMM_ERR_UNSUPPORTED;
+        return L.slots ? launch<12, false, 640, false, 4, 5, true, -1>(L, a, B, st) : launch<12, false, 640, false, 4, 5, false, -1>(L, a, B, st);
     }
     if (L.sb) {
         if (L.tpg == 12 && L.maxt == 640) return launch_b<12, 640, true>(L, a, B, st);
@@ -86,8 +95,8 @@ int mg_lds_iteration(const LdsLaunch& L, const LdsArgs& a, int B, hipStream_t st
                     case 6: return launch<8, false, 1024, false, 4, 5, false, 3>(L, a, B, st);
                     case 7: return launch<8, false, 1024, false, 4, 5, true, 3>(L, a, B, st);
                 }
-                mg_set_error("lds: the uniform-row instances hold W_d^T rows of up to %d entries", 1 + LDS_NLEAD + 6);
-                return MGADMM_ERR_UNSUPPORTED;
+                // longer tails: pair count at run time
+                return L.slots ? launch<8, false, 1024, false, 4, 5, true, -1>(L, a, B, st) : launch<8, false, 1024, false, 4, 5, false, -1>(L, a, B, st);
             }
             return launch_b<8, 1024, false>(L, a, B, st);
         case 12: return launch_b<12, 1024, false>(L, a, B, st);

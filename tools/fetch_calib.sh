@@ -13,7 +13,8 @@ for tag, d in (("FETCH_SIZE", "/tmp/calib_f"), ("WRITE_SIZE", "/tmp/calib_w")):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != tag or "k_stream_read" not in r["Kernel_Name"]:
             continue
-        width = {"float>": 4, "float2>": 8, "float4>": 16}[[k for k in ("float4>", "float2>", "float>") if k in r["Kernel_Name"].replace("HIP_vector_type<float, 2u>", "float2").replace("HIP_vector_type<float, 4u>", "float4")][0]]
+        nm = r["Kernel_Name"].replace(" ", "")
+        width = 16 if "float,4u" in nm or "float4" in nm else (8 if "float,2u" in nm or "float2" in nm else 4)
         res.setdefault(str(width), {})[tag + "_KB"] = float(r["Counter_Value"])
 known_r, known_w = float(1 << 30), 4.0 * 65536 * 256
 for w, d in res.items():
