@@ -1475,7 +1475,7 @@ struct Engine : EngineBase {
         // time per solver.  The sum of a row runs in the chosen order (fixed per graph: repeatable).
         // MGADMM_LDS_TABLE_ORDER=1 keeps the table order, MGADMM_LDS_BANK_SEARCH=<steps> sets the search length (0: greedy only).
         const bool bank_order = !band && best % 4 == 0 && ((lds.TS / 4) & 1) && !getenv("MGADMM_LDS_TABLE_ORDER");
-        long search_steps = 1500;
+        long search_steps = 4000;
         if (const char* e = getenv("MGADMM_LDS_BANK_SEARCH")) search_steps = atol(e);
         // order[e] = index into h.col / h.val of the entry the kernel reads at position e (real rows only; ghosts' rows follow as they are)
         auto slot_order = [&](const HostCsr& h, ldsbank::Stream stream) {
