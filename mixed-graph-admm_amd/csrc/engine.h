@@ -274,17 +274,20 @@ struct Engine : EngineBase {
     template <int VECT_, int NW_, int MA_, int MQ_, int MP_, int MINW_>
     struct ClG { static constexpr int VECT = VECT_, NW = NW_, MA = MA_, MQ = MQ_, MP = MP_, MINW = MINW_; };
     // measured on cfg3 (N = 10 000, B = 512), SpMM + LHS launch / with the folded vector update:
-    //   geometry 0  365 us / 711 us (13 spilled VGPRs in the folded form)      geometry 1  380 us / 644 us      geometry 2  700 us / -
-    typedef ClG<4, 8, 2, 4, 6, 4> ClG0;     // 16 / 32 / 48 rows of 256 columns: 80 KiB (float), two workgroups fill the 160 KiB LDS exactly
+    //   geometry 1  380 us / 644 us      geometry 2  700 us / -      (a 16 / 32 / 48-row geometry 0 of 80 KiB ran 365 us / 711 us and
+    //   spilled 52 VGPRs in the folded form: removed in round 3)
     typedef ClG<4, 8, 2, 4, 5, 4> ClG1;     // 16 / 32 / 40 rows of 256 columns: 72 KiB (float), two workgroups per CU   (default)
-    typedef ClG<1, 8, 8, 11, 15, sizeof(S) == 4 ? 6 : 2> ClG2;   // 64 / 88 / 120 rows of 64 columns: 52 KiB (float) / 104 KiB (double)
+    typedef ClG<1, 8, 8, 11, 15, sizeof(S) == 4 ? 4 : 2> ClG2;   // 64 / 88 / 120 rows of 64 columns: 52 KiB (float) / 104 KiB (double); float: 128 VGPRs (6 waves per SIMD = 80 VGPRs spilled 87-100 of them in the folded form)
+    typedef ClG<2, 8, 4, 8, 10, 4> ClG3;    // 32 / 64 / 80 rows of 128 columns: 72 KiB (float): twice the rows per tile, a smaller halo share
+    typedef ClG<4, 16, 2, 3, 4, 4> ClG4;    // 32 / 48 / 64 rows of 256 columns, 16 waves: 112 KiB (float), one workgroup per CU
     static constexpr int CL_GT = 12;        // W_d^T slots per row; W_d slots: 6 (no test at all) when no row is longer, else 8
     int cl_gd = 8;
     int cl_geom = sizeof(S) == 4 ? 1 : 2;   // float64: the narrow geometry (104 KiB)
     void cl_dims(int& vect, int& nw, int& ma, int& mq, int& mp) const {
         switch (cl_geom) {
-            case 0: vect = ClG0::VECT; nw = ClG0::NW; ma = ClG0::MA; mq = ClG0::MQ; mp = ClG0::MP; break;
             case 1: vect = ClG1::VECT; nw = ClG1::NW; ma = ClG1::MA; mq = ClG1::MQ; mp = ClG1::MP; break;
+            case 3: vect = ClG3::VECT; nw = ClG3::NW; ma = ClG3::MA; mq = ClG3::MQ; mp = ClG3::MP; break;
+            case 4: vect = ClG4::VECT; nw = ClG4::NW; ma = ClG4::MA; mq = ClG4::MQ; mp = ClG4::MP; break;
             default: vect = ClG2::VECT; nw = ClG2::NW; ma = ClG2::MA; mq = ClG2::MQ; mp = ClG2::MP; break;
         }
     }
@@ -295,7 +298,7 @@ struct Engine : EngineBase {
     }
     void cldr_prepare() {
         cldr_dev.state = -1;
-        if (const char* e = getenv("MGADMM_CLDR_GEOM")) { const int v = atoi(e); if (v >= 0 && v <= 2) cl_geom = v; }
+        if (const char* e = getenv("MGADMM_CLDR_GEOM")) { const int v = atoi(e); if (v >= 1 && v <= 4 && (v <= 2 || sizeof(S) == 4)) cl_geom = v; }
         int vect, nw, ma, mq, mp;
         cl_dims(vect, nw, ma, mq, mp);
         if ((size_t)nw * (mq + mp) * 64 * vect * sizeof(S) > 150 * 1024) { cl_geom = 2; cl_dims(vect, nw, ma, mq, mp); }
@@ -307,7 +310,9 @@ struct Engine : EngineBase {
             if (A.rowptr[i + 1] - A.rowptr[i] > 6) cl_gd = 8;
         CldrCaps caps{nw * ma, nw * mq, nw * mp, cl_gd, CL_GT};
         CldrTiles tl;
-        if (!build_cldr_tiles(A, At, g->cluster_starts, caps, tl)) return;
+        int row_limit = 0;
+        if (const char* e = getenv("MGADMM_CLDR_ROWS")) row_limit = atoi(e);
+        if (!build_cldr_tiles(A, At, g->cluster_starts, caps, tl, row_limit)) return;
         if (getenv("MGADMM_TILE_STATS"))
             fprintf(stderr, "[mgadmm] cldr tiles (geometry %d): %d tiles, rows/tile %.1f, |C1| %.1f, |C2| %.1f (caps %d/%d/%d): reads %.2fx, q recomputed %.2fx\n",
                     cl_geom, tl.NT, (double)N / tl.NT, (double)tl.sumC1 / tl.NT, (double)tl.sumC2 / tl.NT, caps.Rcap, caps.C1cap, caps.C2cap,
@@ -372,8 +377,9 @@ struct Engine : EngineBase {
         int rc;
         if constexpr (sizeof(S) == 4) {
             switch (cl_geom) {
-                case 0: rc = rows_cldr_g<ClG0, E, SRC>(q, mk_src(ClG0()), live, a...); break;
                 case 1: rc = rows_cldr_g<ClG1, E, SRC>(q, mk_src(ClG1()), live, a...); break;
+                case 3: rc = rows_cldr_g<ClG3, E, SRC>(q, mk_src(ClG3()), live, a...); break;
+                case 4: rc = rows_cldr_g<ClG4, E, SRC>(q, mk_src(ClG4()), live, a...); break;
                 default: rc = rows_cldr_g<ClG2, E, SRC>(q, mk_src(ClG2()), live, a...); break;
             }
         } else {

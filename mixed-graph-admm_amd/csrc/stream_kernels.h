@@ -48,6 +48,52 @@ __device__ __forceinline__ void stv(S* p, const Vec<S, V>& x) {
     }
 }
 
+// the same through a WAVE-UNIFORM base pointer + a 32-bit per-lane byte offset: the scalar-base form of global_load /
+// global_store (base in an SGPR pair, one VGPR of offset shared by every row a lane touches) instead of a 64-bit address
+// in a VGPR pair per access
+template <typename S, int V>
+__device__ __forceinline__ Vec<S, V> ldv_u(const S* ubase, unsigned lane_bytes) {
+    typedef S vt __attribute__((ext_vector_type(V)));
+    const __attribute__((address_space(1))) char* b = (const __attribute__((address_space(1))) char*)ubase;
+    Vec<S, V> r;
+    if constexpr (V == 1) {
+        r.v[0] = *reinterpret_cast<const __attribute__((address_space(1))) S*>(b + lane_bytes);
+    } else {
+        const vt t = *reinterpret_cast<const __attribute__((address_space(1))) vt*>(b + lane_bytes);
+#pragma unroll
+        for (int k = 0; k < V; ++k) r.v[k] = t[k];
+    }
+    return r;
+}
+
+template <typename S, int V>
+__device__ __forceinline__ void stv_u(S* ubase, unsigned lane_bytes, const Vec<S, V>& x) {
+    typedef S vt __attribute__((ext_vector_type(V)));
+    __attribute__((address_space(1))) char* b = (__attribute__((address_space(1))) char*)ubase;
+    if constexpr (V == 1) {
+        __builtin_nontemporal_store(x.v[0], reinterpret_cast<__attribute__((address_space(1))) S*>(b + lane_bytes));
+    } else {
+        vt t;
+#pragma unroll
+        for (int k = 0; k < V; ++k) t[k] = x.v[k];
+        __builtin_nontemporal_store(t, reinterpret_cast<__attribute__((address_space(1))) vt*>(b + lane_bytes));
+    }
+}
+// where an epilogue finds its element of a row: a flat element offset (k_rows / k_tile), or a wave-uniform element offset
+// + the lane's byte offset inside the row (k_cldr: scalar-base accesses)
+struct OffSplit {
+    size_t u;
+    unsigned lb;
+};
+template <typename S, int V>
+__device__ __forceinline__ Vec<S, V> ldo(const S* p, size_t off) { return ldv<S, V>(p + off); }
+template <typename S, int V>
+__device__ __forceinline__ Vec<S, V> ldo(const S* p, const OffSplit& o) { return ldv_u<S, V>(p + o.u, o.lb); }
+template <typename S, int V>
+__device__ __forceinline__ void sto(S* p, size_t off, const Vec<S, V>& x) { stv<S, V>(p + off, x); }
+template <typename S, int V>
+__device__ __forceinline__ void sto(S* p, const OffSplit& o, const Vec<S, V>& x) { stv_u<S, V>(p + o.u, o.lb, x); }
+
 struct Geom {
     int T, N, B, Bp;
     int VEC, CH;         // columns per lane; column chunks of 64*VEC
@@ -736,6 +782,12 @@ struct CldrSrcFold {
     const S* beta;
 };
 
+#ifndef MG_CLDR_EARLY
+#define MG_CLDR_EARLY 0
+#endif
+#ifndef MG_CLDR_BATCH
+#define MG_CLDR_BATCH 1
+#endif
 // MINW: waves per SIMD the register allocation must leave room for (= resident workgroups per CU * NW / 4)
 template <typename S, int VECT, class Epi, class Src, int NW, int MA, int MQ, int MP, int GD, int GT, int MINW>
 __global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, Src src, Epi epi_in,
@@ -825,58 +877,95 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, 
         for (int k = 0; k < MP; ++k)
 #pragma unroll
             for (int v = 0; v < VECT; ++v) pn[k].v[v] = S(0);     // row slots past |C2| are never loaded
-        // rows of time slice tt -> registers
-        auto request = [&](int tt) {
-            if (tt < g.T) {
-                const size_t so = (size_t)tt * slice + col0;
+        // rows of time slice tt -> registers, in TWO BATCHES: the wave's own rows (k < MA: r, p_old, x), then -- when those have
+        // arrived -- its halo rows.  BRANCH-FREE: a row slot past |C2| reads the tile's first row instead (an L1 / L2 hit, never
+        // used).  Rounds 1-2 tested every slot: each load sat in its own basic block and the compiler put s_waitcnt vmcnt(0)
+        // in front of it -- the (up to) 12 row loads of a step went out one after the other, a full round trip each (7 in
+        // a row).  All 12 at once is worse still (measured: 974 us against 755, 3.79 GB fetched against 2.20): the copies of a
+        // halo row that several tiles of the XCD request at the same moment all miss in its L2.  Own rows first, halo rows a
+        // round trip later keeps the order that makes the halo copies hit (their owners asked for them a moment earlier).
+        const unsigned lane_b = (unsigned)(lane * VECT * sizeof(S));          // per-lane byte offset inside a row of the chunk
+        auto request_rows = [&](int tt, const int k0, const int k1, bool own) {
+            const size_t so = (size_t)tt * slice + (size_t)chunk * 64 * VECT;     // wave-uniform
+            // (opaque copy of the lane offset, made next to the loads: the optimiser otherwise adds it to the loop-invariant
+            // part of every row address OUTSIDE the time loop and keeps a 64-bit address per row in vector registers)
+            unsigned lb = lane_b;
+            asm volatile("" : "+v"(lb));
 #pragma unroll
-                for (int k = 0; k < MP; ++k) {
+            for (int k = 0; k < MP; ++k) {
+                if (k >= k0 && k < k1) {
                     const int hr = __builtin_amdgcn_readlane(hrow, k);
-                    if (hr >= 0) {
-                        pn[k] = ldv<S, VECT>(src.in + so + (size_t)hr * g.Bp);
-                        if constexpr (Src::FOLD) po[k] = ldv<S, VECT>(src.p_old + so + (size_t)hr * g.Bp);
-                    }
+                    const size_t ro = so + (size_t)(hr >= 0 ? hr : n0) * g.Bp;
+                    pn[k] = ldv_u<S, VECT>(src.in + ro, lb);
+                    if constexpr (Src::FOLD) po[k] = ldv_u<S, VECT>(src.p_old + ro, lb);
                 }
-                if constexpr (Src::FOLD) {
+            }
+            if constexpr (Src::FOLD) {
+                if (own) {
 #pragma unroll
                     for (int k = 0; k < MA; ++k)
-                        if (wave + NW * k < R) xo[k] = ldv<S, VECT>(src.x + so + (size_t)(n0 + wave + NW * k) * g.Bp);
+                        xo[k] = ldv_u<S, VECT>(src.x + so + (size_t)(n0 + (wave + NW * k < R ? wave + NW * k : 0)) * g.Bp, lb);
                 }
+            }
+        };
+        auto request = [&](int tt) {
+            if (tt < g.T) {
+#if MG_CLDR_BATCH == 0
+                request_rows(tt, 0, MP, true);
+#elif MG_CLDR_BATCH == 1
+                request_rows(tt, 0, MA, true);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                request_rows(tt, MA, MP, false);
+#elif MG_CLDR_BATCH == 2
+                request_rows(tt, 0, 1, true);
+#pragma unroll
+                for (int k = 1; k < MP; ++k) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    request_rows(tt, k, k + 1, false);
+                }
+#else
+                request_rows(tt, 0, MA, true);
+#pragma unroll
+                for (int k = MA; k < MP; ++k) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    request_rows(tt, k, k + 1, false);
+                }
+#endif
             }
         };
         // FOLD: the requested rows of slice tt become p_new = r + beta p_old; own rows: x += alpha p_old, p_new stored
         auto combine = [&](int tt) {
             if constexpr (Src::FOLD) {
+                unsigned lbs = lane_b;
+                asm volatile("" : "+v"(lbs));
 #pragma unroll
                 for (int k = 0; k < MP; ++k) {
-                    const int hr = __builtin_amdgcn_readlane(hrow, k);
-                    if (hr >= 0) {
-                        Vec<S, VECT> pv;
+                    Vec<S, VECT> pv;
 #pragma unroll
-                        for (int v = 0; v < VECT; ++v) pv.v[v] = fma(fb[v], po[k].v[v], pn[k].v[v]);
-                        if (k < MA) {
-                            if (wave + NW * k < R) {
-                                const size_t off = (size_t)tt * slice + (size_t)(n0 + wave + NW * k) * g.Bp + col0;
-                                Vec<S, VECT> xv;
+                    for (int v = 0; v < VECT; ++v) pv.v[v] = fma(fb[v], po[k].v[v], pn[k].v[v]);
+                    if (k < MA) {
+                        if (wave + NW * k < R) {
+                            const size_t uoff = (size_t)tt * slice + (size_t)(n0 + wave + NW * k) * g.Bp + (size_t)chunk * 64 * VECT;
+                            Vec<S, VECT> xv;
 #pragma unroll
-                                for (int v = 0; v < VECT; ++v) xv.v[v] = fma(fa[v], po[k].v[v], xo[k < MAF ? k : 0].v[v]);
-                                stv<S, VECT>(src.x + off, xv);
-                                stv<S, VECT>(src.p_new + off, pv);
-                            }
+                            for (int v = 0; v < VECT; ++v) xv.v[v] = fma(fa[v], po[k].v[v], xo[k < MAF ? k : 0].v[v]);
+                            stv_u<S, VECT>(src.x + uoff, lbs, xv);
+                            stv_u<S, VECT>(src.p_new + uoff, lbs, pv);
                         }
-                        pn[k] = pv;
                     }
+                    pn[k] = pv;
                 }
             }
+        };
+        // P image <- the requested rows (every slot: the rows past |C2| of the image are never gathered)
+        auto store_p = [&]() {
+#pragma unroll
+            for (int k = 0; k < MP; ++k) stl<S, VECT>(Pimg + (size_t)(wave + NW * k) * W + lane * VECT, pn[k]);
         };
         // prologue: x_0 -> P image, q_0 = 0, request x_1
         request(0);
         combine(0);
-#pragma unroll
-        for (int k = 0; k < MP; ++k) {
-            const int hr = __builtin_amdgcn_readlane(hrow, k);
-            if (hr >= 0) stl<S, VECT>(Pimg + (size_t)(wave + NW * k) * W + lane * VECT, pn[k]);
-        }
+        store_p();
 #pragma unroll
         for (int k = 0; k < MA; ++k) {
             pc[k] = pn[k];
@@ -906,6 +995,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, 
                 }
             }
             __syncthreads();                              // Q complete; every gather from P is done
+#if MG_CLDR_EARLY
+            // ---- phase C, early-request form: P <- x_{t+1} and the request of x_{t+2} first (the loads fly during the gathers and
+            // the epilogue), x_{t+1} of the own rows comes back from the P image afterwards
+            if (nxt) store_p();
+            request(t + 2);
+#endif
             // ---- phase C: own rows of l_t through the epilogue, then P <- x_{t+1} and the request of x_{t+2}
             const S selfc = (t > 0 || g.q1) ? S(1) : S(0);
             Vec<S, VECT> lv[MA];
@@ -918,17 +1013,26 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, 
 #pragma unroll
                 for (int v = 0; v < VECT; ++v) lv[k].v[v] = selfc * qp[k].v[v] - sum.v[v];
             }
+            {
+                unsigned lbe = lane_b;
+                asm volatile("" : "+v"(lbe));
 #pragma unroll
-            for (int k = 0; k < MA; ++k) {
-                const int l = wave + NW * k;
-                if (l < R) epi.row(t, ((size_t)t * g.N + n0 + l) * g.Bp + col0, pc[k], lv[k], acc);
+                for (int k = 0; k < MA; ++k) {
+                    const int l = wave + NW * k;
+                    if (l < R) epi.row(t, OffSplit{((size_t)t * g.N + n0 + l) * g.Bp + (size_t)chunk * 64 * VECT, lbe}, pc[k], lv[k], acc);
+                }
             }
+#if MG_CLDR_EARLY
             if (nxt) {
 #pragma unroll
-                for (int k = 0; k < MP; ++k) {
-                    const int hr = __builtin_amdgcn_readlane(hrow, k);
-                    if (hr >= 0) stl<S, VECT>(Pimg + (size_t)(wave + NW * k) * W + lane * VECT, pn[k]);
+                for (int k = 0; k < MA; ++k) {
+                    pc[k] = ldv<S, VECT>(Pimg + (size_t)(wave + NW * k) * W + lane * VECT);       // this wave's own store: no barrier
+                    qp[k] = qn[k];
                 }
+            }
+#else
+            if (nxt) {
+                store_p();
 #pragma unroll
                 for (int k = 0; k < MA; ++k) {
                     pc[k] = pn[k];
@@ -936,6 +1040,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, 
                 }
             }
             request(t + 2);
+#endif
             __syncthreads();                              // P = x_{t+1} complete; every gather from Q is done
         }
     }
@@ -973,7 +1078,8 @@ struct EpiStore {  // out = l
     static constexpr bool HAS_PRE = false;
     S* out;
     __device__ void begin(int) {}
-    __device__ void row(int, size_t off, const Vec<S, VEC>&, const Vec<S, VEC>& l, S (*)[VEC]) { stv<S, VEC>(out + off, l); }
+    template <class O>
+    __device__ void row(int, O off, const Vec<S, VEC>&, const Vec<S, VEC>& l, S (*)[VEC]) { sto<S, VEC>(out, off, l); }
 };
 
 // Ap = HtH p + c1 p + c2 l ; acc0 += p.Ap       (LHS_x / LHS_zu / LHS_zd applied to the CG direction,
@@ -989,20 +1095,22 @@ struct EpiLhs {
     S c1, c2;
     __device__ void begin(int) {}
     __device__ Vec<S, VEC> pre(size_t off) const {
-        if (p) return ldv<S, VEC>(p + off);
+        if (p) return ldo<S, VEC>(p, off);
         Vec<S, VEC> z;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) z.v[v] = S(0);
         return z;
     }
-    __device__ void row(int t, size_t off, const Vec<S, VEC>& self, const Vec<S, VEC>& l, S (*acc)[VEC]) {
-        row_pre(t, off, self, l, acc, p ? ldv<S, VEC>(p + off) : self);
+    template <class O>
+    __device__ void row(int t, O off, const Vec<S, VEC>& self, const Vec<S, VEC>& l, S (*acc)[VEC]) {
+        row_pre(t, off, self, l, acc, p ? ldo<S, VEC>(p, off) : self);
     }
-    __device__ void row_pre(int t, size_t off, const Vec<S, VEC>& self, const Vec<S, VEC>& l, S (*acc)[VEC],
+    template <class O>
+    __device__ void row_pre(int t, O off, const Vec<S, VEC>& self, const Vec<S, VEC>& l, S (*acc)[VEC],
                             const Vec<S, VEC>& pin) {
         const Vec<S, VEC> pv = p ? pin : self;
         Vec<S, VEC> d;
-        if (mask) d = ldv<S, VEC>(mask + off);
+        if (mask) d = ldo<S, VEC>(mask, off);
         else {
             const S dd = (hth && t < t_in) ? S(1) : S(0);
 #pragma unroll
@@ -1014,7 +1122,7 @@ struct EpiLhs {
             o.v[v] = d.v[v] * pv.v[v] + c1 * pv.v[v] + c2 * l.v[v];
             acc[0][v] += pv.v[v] * o.v[v];
         }
-        stv<S, VEC>(Ap + off, o);
+        sto<S, VEC>(Ap, off, o);
     }
 };
 
@@ -1030,11 +1138,12 @@ struct EpiCgInit {
     int hth, t_in;
     S c1, c2;
     __device__ void begin(int) {}
-    __device__ void row(int t, size_t off, const Vec<S, VEC>& self, const Vec<S, VEC>& l, S (*acc)[VEC]) {
-        const Vec<S, VEC> xv = x0 ? ldv<S, VEC>(x0 + off) : self;
-        const Vec<S, VEC> bv = ldv<S, VEC>(rhs + off);
+    template <class O>
+    __device__ void row(int t, O off, const Vec<S, VEC>& self, const Vec<S, VEC>& l, S (*acc)[VEC]) {
+        const Vec<S, VEC> xv = x0 ? ldo<S, VEC>(x0, off) : self;
+        const Vec<S, VEC> bv = ldo<S, VEC>(rhs, off);
         Vec<S, VEC> d;
-        if (mask) d = ldv<S, VEC>(mask + off);
+        if (mask) d = ldo<S, VEC>(mask, off);
         else {
             const S dd = (hth && t < t_in) ? S(1) : S(0);
 #pragma unroll
@@ -1047,9 +1156,9 @@ struct EpiCgInit {
             rv.v[v] = bv.v[v] - ax;
             acc[0][v] += rv.v[v] * rv.v[v];
         }
-        stv<S, VEC>(r + off, rv);
-        stv<S, VEC>(p + off, rv);
-        stv<S, VEC>(x + off, xv);
+        sto<S, VEC>(r, off, rv);
+        sto<S, VEC>(p, off, rv);
+        sto<S, VEC>(x, off, xv);
     }
 };
 
@@ -1336,7 +1445,7 @@ __global__ __launch_bounds__(1024) void k_reduce(const S* __restrict__ partials,
     // RB partial rows per trip: the loads are issued together (the kernel is pure latency: Bp/64 workgroups, up
     // to ~80 rows per wave on the 10k-node graph, ~800 on the 100k-node one), the additions stay in row order
     // -- same sums, bit for bit
-    constexpr int RB = NRED <= 2 ? 16 : 8;
+    constexpr int RB = NRED <= 2 ? 16 : (NRED * sizeof(S) > 32 ? 4 : 8);     // at most 48 registers of loads in flight
     int p = wave;
     for (; p + (RB - 1) * 16 < P; p += RB * 16) {
         S v[RB][NRED];
@@ -1370,6 +1479,7 @@ __global__ __launch_bounds__(1024) void k_reduce(const S* __restrict__ partials,
     }
     __syncthreads();
     if (wave == 0) {
+#pragma unroll 3      // fully unrolled the compiler reads all 15 * NRED doubles first (NRED = 6: 44 VGPRs spilled)
         for (int w = 0; w < 15; ++w)
 #pragma unroll
             for (int r = 0; r < NRED; ++r) s[r] += sm[w][r][lane];

@@ -203,3 +203,17 @@ def test_cfg4_solve_finite_repeatable_and_vs_oracle_windows(cfg4):
     assert torch.equal(x1, x2) and np.array_equal(h1, np.array(blk.p_res_list))      # bitwise repeatable
     ws = blk.workspace_bytes()
     assert 40e9 < ws < 80e9, ws                                                       # ~52 GB of the 288 GB
+
+
+def test_cfg4_default_quirks_vs_oracle_windows():
+    """The same slice with the reference's quirks ON (bug_compat=True, the default of both sides: Q1 keeps the identity on
+    the t = 0 block of Ldr_T, ADMM.py:221-222, which enters RHS_x): 2 windows x 2 iterations against the oracle."""
+    blk, n, B, cl, info = _problem("cfg4")
+    b = _bench()
+    y = b.synth_y(n, B, 12, seed=1, offset=0, device=torch.device("cuda"))
+    x = _solve(blk, y, 2)
+    idx = np.array([0, B - 1])
+    o = _oracle(blk, cl, info)
+    xo = o.combined_loop(y[torch.as_tensor(idx, device=y.device)].double().cpu().numpy(), n_iters=2)
+    _check_windows("cfg4-quirks", blk, x, idx, o, xo)
+    blk.close()

@@ -538,7 +538,7 @@ def test_tiled_kernel_full_solves(g4_meta, g4_solves, dt, xtol, htol, slack, mon
 
 
 # ------------------------------------------------------------------ fused cLdr kernel (k_cldr): every tile geometry
-@pytest.mark.parametrize("geom,B,fold", [(0, 256, 1), (1, 256, 1), (1, 256, 0), (2, 70, 1), (2, 256, 1)])
+@pytest.mark.parametrize("geom,B,fold", [(1, 256, 1), (1, 256, 0), (2, 70, 1), (2, 70, 0), (2, 256, 1), (3, 256, 1), (3, 256, 0), (4, 256, 1), (4, 256, 0)])
 def test_fused_cldr_kernel_geometries_vs_oracle(geom, B, fold, monkeypatch):
     """k_cldr = Ldr^T Ldr in one pass with q recomputed on the tile halo, with and without the CG vector update folded
     into its loads (CldrSrcFold), in each of its tile geometries (256 / 64 columns per row): operators, one CG solve and a

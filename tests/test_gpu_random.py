@@ -92,9 +92,21 @@ def test_random_problem_matches_oracle(seed):
         floor = (1e-7 if htol >= 1e-4 else 1e-13) * float(np.linalg.norm(xo))
         np.testing.assert_allclose(np.array(blk.p_res_list), np.array(ho.p_res_list), rtol=htol, atol=floor, err_msg=tag)
         np.testing.assert_allclose(np.array(blk.d_res_list), np.array(ho.d_res_list), rtol=htol, atol=floor, err_msg=tag)
-        got = np.array([v.tolist() if torch.is_tensor(v) else [int(v)] for v in blk.CG_iter_zu]).reshape(iters, -1)   # ints at B = 1
-        ref = np.array(ho.CG_iter_zu).reshape(iters, -1)
-        # tiny systems (N*T of a few dozen unknowns) terminate by exhausting the Krylov space in float64; float32
-        # needs an iteration or two more to push the recursive residual below 1e-8
-        assert np.abs(got - ref).max() <= (slack if slack == 0 or meta["n"] * meta["T"] > 100 else 2), tag
+        # CG iteration counts of all three solves (ADMM.py:572-591): equal in float64; within 1 in float32 on the generic
+        # graphs ('DGTV' / 'UT': 2-iteration diagonal x solves, one more unit).  Where the float64 count is a
+        # finite-termination count -- line / skip3 graphs (a handful of distinct eigenvalues: seed 6 stops after exactly T = 8
+        # iterations) and systems of at most a few hundred unknowns (seed 19: 20 unknowns, 4 iterations) -- float32 loses the
+        # exact termination and runs on until the recursive residual passes 1e-8: bounded by twice the count there.
+        for nm in ("CG_iter_x", "CG_iter_zu", "CG_iter_zd"):
+            if nm == "CG_iter_zd" and abl == "DGLR":
+                continue
+            got = np.array([v.tolist() if torch.is_tensor(v) else [int(v)] for v in getattr(blk, nm)]).reshape(iters, -1)   # ints at B = 1
+            ref = np.array(getattr(ho, nm)).reshape(iters, -1)
+            if slack == 0:
+                assert (got == ref).all(), tag + " " + nm
+            elif mode in ("line", "skip3") or meta["n"] * meta["T"] <= 400:
+                assert (got >= ref - 1).all() and (got <= 2 * ref + 1).all(), tag + " " + nm
+            else:
+                lim = slack + (1 if nm == "CG_iter_x" and abl in ("DGTV", "UT") else 0)
+                assert np.abs(got - ref).max() <= lim, tag + " " + nm
         blk.close()

@@ -114,6 +114,21 @@ def main():
         ff = fetch_factor(k, calib)
         per[k] = (ff * f + w) * 1024.0
         L.append(f"{k:44s} {n:6d} {f:10.0f} {w:10.0f} {ff:7.2f} {per[k] / 1e6:10.1f} {du:12.1f} {per[k] / max(du, 1e-9) / 1e6:7.2f}")
+    if os.path.isdir(d + '/fold0'):
+        # the same command under MGADMM_FOLD=0: the CG vector update runs in its own kernel and the SpMM launches carry their
+        # own bytes only -- cfg3 leg: T*N*B = 24 * 10 000 * 512 elements; cLdr = 2 applications (read p, write A p twice over:
+        # 16 B/element), Lu = 1 application (8 B/element)
+        d0 = durations(d + '/fold0')
+        elems = 24 * 10000 * 512
+        L += ["", "# SpMM-only launches (same command under MGADMM_FOLD=0: p = r + beta p, x += alpha p in their own k_rows<EpiPUpdate> launch);",
+              "# algorithmic bytes: 16 B/element for cLdr (k_cldr: Ldr then Ldr^T in one pass), 8 B/element for Lu (k_tile), 20 B/element for the vector update",
+              f"{'kernel':44s} {'n_live':>6s} {'live_avg_us':>12s} {'alg_GB':>8s} {'TB/s':>7s} {'of 8 TB/s':>10s}"]
+        for k in sorted(d0, key=lambda k: -sum(d0[k])):
+            bpe = 16 if (k.startswith('k_cldr') and 'EpiLhs' in k) else 8 if (k.startswith('k_tile') and 'EpiLhs' in k) else 20 if 'EpiPUpdate' in k else 0
+            if not bpe:
+                continue
+            lm, ln = live_mean(d0[k])
+            L.append(f"{k:44s} {ln:6d} {lm:12.1f} {bpe * elems / 1e9:8.3f} {bpe * elems / lm / 1e6:7.2f} {bpe * elems / lm / 1e6 / 8.0:10.2f}")
     open(out, 'w').write("\n".join(L) + "\n")
     spmm = [k for k in per if is_spmm_in_cg(k)]
     wts = {k: live_mean(fetch[k])[1] for k in spmm}

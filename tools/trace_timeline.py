@@ -1,10 +1,11 @@
-"""Timeline of one rocprofv3 --kernel-trace run: for every kernel launch its start relative to the previous launch's end
-(idle gap of the device between two kernels) and its duration, printed for the launches between two consecutive launches
-of a named anchor kernel (default k_admm_lds), averaged over all such periods.
+"""Timeline of one rocprofv3 --kernel-trace run: for every kernel launch between two consecutive launches of a named anchor
+kernel (default k_admm_lds) its start relative to the START of the anchor launch and its duration, averaged over all such
+periods (the metric kernels of the LDS path run on a side stream BESIDE the next anchor launch: offsets inside the anchor's
+duration are overlap, not idle time).
 
     python tools/trace_timeline.py <trace dir> [anchor substring]
 
-Used to see what the 2.73 ms of a cfg2 ADMM iteration consist of beside the 2.57 ms k_admm_lds launch.
+Used to see what the period of a cfg2 launch (7 ADMM iterations of the whole batch) consists of beside the k_admm_lds launch itself.
 """
 import collections, csv, glob, sys
 
@@ -30,16 +31,15 @@ def main():
         n += 1
         period += (rows[b][0] - rows[a][0]) / 1e3
         for j in range(a, b):
-            prev_end = rows[j - 1][1] if j > 0 else rows[j][0]
-            acc[j - a][0] += (rows[j][0] - prev_end) / 1e3
+            acc[j - a][0] += (rows[j][0] - rows[a][0]) / 1e3
             acc[j - a][1] += (rows[j][1] - rows[j][0]) / 1e3
     print(f"# {n} periods of {len(seq)} launches, anchor '{anchor}', mean period {period / n:.1f} us")
-    print(f"{'kernel':50s} {'gap_before_us':>14s} {'duration_us':>12s}")
-    tg = td = 0.0
+    print(f"{'kernel':50s} {'start_us':>14s} {'duration_us':>12s}")
+    td = 0.0
     for name, (g, du) in zip(seq, acc):
         print(f"{name:50s} {g / n:14.1f} {du / n:12.1f}")
-        tg += g / n; td += du / n
-    print(f"{'sum':50s} {tg:14.1f} {td:12.1f}")
+        td += du / n
+    print(f"{'sum of durations':50s} {'':14s} {td:12.1f}")
 
 
 if __name__ == '__main__':
