@@ -538,12 +538,23 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
             else if (op.self_mode == SELF_LDRT) selfc = (t > 0 || op.q1) ? S(1) : S(0);
             // 1. requests of this step, in the order they are needed: halo rows of the gathered slice, the
             //    epilogue's operand rows, and the own rows of the NEXT step
+            // (halo slots in two branch-free batches -- the first two slots of the wave, then the other three if the wave has
+            // any: a slot that is not in use reads the tile's first row and is never gathered.  With a test per slot every load
+            // sat in its own basic block behind an s_waitcnt vmcnt(0): the halo rows left one after the other, see k_cldr)
             Vec<S, VEC> hv[TILE_HPW];
             if (tvalid) {
+                const size_t hb = (size_t)ts * g.N * g.Bp + col0;
 #pragma unroll
-                for (int k = 0; k < TILE_HPW; ++k) {
+                for (int k = 0; k < 2 && k < TILE_HPW; ++k) {
                     const int hr = __builtin_amdgcn_readlane(hrow, k);
-                    if (hr >= 0) hv[k] = folded((size_t)(tvalid ? ts : t) * g.N * g.Bp + col0 + (size_t)hr * g.Bp);
+                    hv[k] = folded(hb + (size_t)(hr >= 0 ? hr : n0) * g.Bp);
+                }
+                if (__builtin_amdgcn_readlane(hrow, 2 < TILE_HPW ? 2 : 0) >= 0) {
+#pragma unroll
+                    for (int k = 2; k < TILE_HPW; ++k) {
+                        const int hr = __builtin_amdgcn_readlane(hrow, k);
+                        hv[k] = folded(hb + (size_t)(hr >= 0 ? hr : n0) * g.Bp);
+                    }
                 }
             }
             Vec<S, VEC> pre[MR];
@@ -566,9 +577,10 @@ __global__ __launch_bounds__(256) void k_tile(TileGeom g, OpDesc op, const int* 
             }
             if (tvalid) {
 #pragma unroll
-                for (int k = 0; k < TILE_HPW; ++k) {
-                    const int hr = __builtin_amdgcn_readlane(hrow, k);
-                    if (hr >= 0) stl<S, VEC>(hdst + (size_t)(wave + 4 * k) * W, hv[k]);
+                for (int k = 0; k < 2 && k < TILE_HPW; ++k) stl<S, VEC>(hdst + (size_t)(wave + 4 * k) * W, hv[k]);
+                if (__builtin_amdgcn_readlane(hrow, 2 < TILE_HPW ? 2 : 0) >= 0) {
+#pragma unroll
+                    for (int k = 2; k < TILE_HPW; ++k) stl<S, VEC>(hdst + (size_t)(wave + 4 * k) * W, hv[k]);
                 }
             }
             if (shift == 0) {                               // Lu gathers from the slice of this step
