@@ -939,9 +939,8 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     // is widened to 64 bits in another basic block, where instruction selection no longer sees that it fits the 32-bit
     // offset operand: every access then gets a 64-bit address in a register pair (16 VGPRs per vector, which went to scratch
     // and were reloaded one by one in front of the loads and stores of the state).
-    const unsigned off0 = c.glb0();
     auto request1 = [&](const float* A, float (&va)[TPG]) {
-        unsigned o = off0;
+        unsigned o = c.glb0();
         MG_PIN_V(o);
 #pragma unroll
         for (int k = 0; k < TPG; ++k) va[k] = ldg(A, o + c.kN4[k]);
@@ -974,8 +973,9 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
     };
     // y, masked: 0 for the rows past its end (t >= ty: read through offset 0) and for ghosts.  (Predicates on the time index are
     // written k < limit - t0: a per-element t0 + k is formed once, kept in TPG registers for the whole trip and spilled.)
-    const int ylim = c.active ? ty - c.t0 : 0;
+    auto ylim_of = [&]() { return c.active ? ty - c.t0 : 0; };
     auto request_y = [&](float (&va)[TPG]) {
+        const int ylim = ylim_of();
         unsigned o = 4u * (unsigned)(c.t0 * Nn + c.ig);
         MG_PIN_V(o);
 #pragma unroll
@@ -1038,6 +1038,17 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         if (br.lane == 0) mred[br.wave * NMRED + m] = w;
     };
 
+    // PHASE FENCE after every solve: the thread's index values become opaque again and what is derived from them is formed
+    // anew.  Without it the optimiser keeps every address it formed before a solve for the phases after it (slot and state
+    // offsets, table-row addresses, lane / wave numbers): values that are live across a CG loop they are not used in.
+    auto refresh = [&]() {
+        MG_PIN_V(tid);
+        MG_PIN_V(c.i); MG_PIN_V(c.ig); MG_PIN_V(c.t0);
+        c.active = tid < a.nthreads;
+        c.so0 = c.active ? 4u * TPG * (unsigned)tid : 0u;
+        br.lane = tid & 63; br.wave = tid >> 6;
+    };
+
     // ---- first iteration only: phi = Ldr x0 (ADMM.py:541); the dual variables were filled by k_init_lds
     if (has_phi && first) {
         float ph[TPG];
@@ -1089,6 +1100,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         else itx = lds_cg<TPG, BAND, 0, SB, NU, ND, TP>(c, br, x, rhs, mk, 1, t_in, cx1, 0.f, max_cg, tol, ah, bh, Bp, nonfinite, R);
     }
     MG_STAMP(3);
+    refresh();
     fetch_u();                // rows of the zu solve
     c.putg(xn, x);
 
@@ -1117,7 +1129,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
         } else {
 #pragma unroll
             for (int k = 0; k < TPG; ++k) {
-                const float e = k < ylim ? x[k] - yv[k] : 0.f;
+                const float e = k < ylim_of() ? x[k] - yv[k] : 0.f;
                 m_rec += e * e;
             }
         }
@@ -1147,6 +1159,7 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
                                                  bh ? bh + hstride : nullptr, Bp, nonfinite, R);
     }
     MG_STAMP(5);
+    refresh();
     fetch_d();                // rows of the zd solve / of the Ldr of the phi prox
     if (has_zd) fetch_t();
     float xr[TPG], zn[TPG], gn[TPG];
@@ -1202,10 +1215,15 @@ __global__ __launch_bounds__(MAXT, (SB && MAXT == 640) ? 5 : 1) void k_admm_lds(
                                                      bh ? bh + 2 * hstride : nullptr, Bp, nonfinite, R);
         }
         MG_STAMP(7);
-        fetch_u();            // rows of the Lu of the GLR term (the W_d rows stay for the Ldr of the prox)
+        refresh();
+        fetch_u();            // rows of the Lu of the GLR term
+        fetch_d();            // the W_d rows of the prox's Ldr again: rows that stay across the solve cannot be pinned in place inside
+                              // its loop -- the loop then works on copies and both sets are alive (8 registers)
         float zo[TPG], gv[TPG];
         request2s(zd, gd, zo, gv);
-        if (has_phi) request2s(phi, gam, zn, gn);
+        // (unconditional, through vectors that exist: a conditional request keeps the zn / gn of before the solve alive across
+        // it -- 16 registers; without the phi term the prox below computes values nobody reads)
+        request2s(has_phi ? phi : zd, has_phi ? gam : gd, zn, gn);
         if (SLOTS) slot_get<TPG>(slot0, tid, nthr, xr);
         else request1(xn, xr);
         float m_pri = 0.f, m_dual = 0.f;
