@@ -280,7 +280,10 @@ struct Engine : EngineBase {
     typedef ClG<1, 8, 8, 11, 15, sizeof(S) == 4 ? 4 : 2> ClG2;   // 64 / 88 / 120 rows of 64 columns: 52 KiB (float) / 104 KiB (double); float: 128 VGPRs (6 waves per SIMD = 80 VGPRs spilled 87-100 of them in the folded form)
     typedef ClG<2, 8, 4, 8, 10, 4> ClG3;    // 32 / 64 / 80 rows of 128 columns: 72 KiB (float): twice the rows per tile, a smaller halo share
     typedef ClG<4, 16, 2, 3, 4, 4> ClG4;    // 32 / 48 / 64 rows of 256 columns, 16 waves: 112 KiB (float), one workgroup per CU
-    static constexpr int CL_GT = 12;        // W_d^T slots per row; W_d slots: 6 (no test at all) when no row is longer, else 8
+    // W_d^T slots per row: 12, or 16 when a row is longer (round 3: the PEMS-like graphs of 600 ... 2000 nodes have rows of 13 and
+    // 14 entries and fell back to the two-pass path; the 16-slot instance is 5 % slower on graphs that do not need it).
+    // W_d slots: 6 (no test at all) when no row is longer, else 8
+    int cl_gt = 12;
     int cl_gd = 8;
     int cl_geom = sizeof(S) == 4 ? 1 : 2;   // float64: the narrow geometry (104 KiB)
     void cl_dims(int& vect, int& nw, int& ma, int& mq, int& mp) const {
@@ -306,9 +309,12 @@ struct Engine : EngineBase {
         if (g->has_perm) { mg_permute_csr(g->hWd, g->perm, g->iperm, A); mg_permute_csr(g->hWdT, g->perm, g->iperm, At); }
         else { A = g->hWd; At = g->hWdT; }
         cl_gd = 6;
-        for (int i = 0; i < N; ++i)
+        cl_gt = 12;
+        for (int i = 0; i < N; ++i) {
             if (A.rowptr[i + 1] - A.rowptr[i] > 6) cl_gd = 8;
-        CldrCaps caps{nw * ma, nw * mq, nw * mp, cl_gd, CL_GT};
+            if (At.rowptr[i + 1] - At.rowptr[i] > 12) cl_gt = 16;
+        }
+        CldrCaps caps{nw * ma, nw * mq, nw * mp, cl_gd, cl_gt};
         CldrTiles tl;
         int row_limit = 0;
         if (const char* e = getenv("MGADMM_CLDR_ROWS")) row_limit = atoi(e);
@@ -358,14 +364,15 @@ struct Engine : EngineBase {
     }
     template <class G, template <typename, int> class E, template <typename, int> class SRC, class... A>
     int rows_cldr_g(const Geom& q, const SRC<S, G::VECT>& src, const int* live, A... a) {
-        return cl_gd == 6 ? rows_cldr_gd<G, 6, E, SRC>(q, src, live, a...) : rows_cldr_gd<G, 8, E, SRC>(q, src, live, a...);
+        if (cl_gt == 12) return cl_gd == 6 ? rows_cldr_gd<G, 6, 12, E, SRC>(q, src, live, a...) : rows_cldr_gd<G, 8, 12, E, SRC>(q, src, live, a...);
+        return cl_gd == 6 ? rows_cldr_gd<G, 6, 16, E, SRC>(q, src, live, a...) : rows_cldr_gd<G, 8, 16, E, SRC>(q, src, live, a...);
     }
-    template <class G, int GD, template <typename, int> class E, template <typename, int> class SRC, class... A>
+    template <class G, int GD, int GT, template <typename, int> class E, template <typename, int> class SRC, class... A>
     int rows_cldr_gd(const Geom& q, const SRC<S, G::VECT>& src, const int* live, A... a) {
         const CldrGeom cg = make_cldr_geom(q);
         CldrMeta mm{cldr_dev.n0, cldr_dev.nC, cldr_dev.rows, cldr_dev.dcol, cldr_dev.dw, cldr_dev.dcnt, cldr_dev.tcol, cldr_dev.tw, cldr_dev.tcnt};
         typedef E<S, G::VECT> Epi;
-        auto fn = k_cldr<S, G::VECT, Epi, SRC<S, G::VECT>, G::NW, G::MA, G::MQ, G::MP, GD, CL_GT, G::MINW>;
+        auto fn = k_cldr<S, G::VECT, Epi, SRC<S, G::VECT>, G::NW, G::MA, G::MQ, G::MP, GD, GT, G::MINW>;
         MG_TRY(allow_dynamic_lds((const void*)fn, 150 * 1024));
         hipLaunchKernelGGL(fn, dim3(cg.grid), dim3(G::NW * 64), cg.lds_bytes, st, cg, mm, src, Epi{a...}, partials, live);
         cur_P = cg.P;
@@ -515,6 +522,7 @@ struct Engine : EngineBase {
             case MGADMM_Q_LDS_SLOTS: *out = lds.slots; break;
             case MGADMM_Q_LDS_CHUNK: *out = std::max(1, std::min(lds_chunk, LDS_MAXJ_POOL)); break;
             case MGADMM_Q_LDS_ROWS: *out = lds.NR; break;
+            case MGADMM_Q_CLDR_SLOTS: *out = cldr_dev.state == 1 ? cl_gt : 0; break;      // (prepared by the first operator application)
             case MGADMM_Q_NNZ_U: *out = g->hWu.nnz(); break;
             case MGADMM_Q_NNZ_D: *out = g->hWd.nnz(); break;
             case MGADMM_Q_NNZ_DT: *out = g->hWdT.nnz(); break;

@@ -810,7 +810,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, 
     constexpr int W = 64 * VECT;
     constexpr int RCAP = NW * MA, C1CAP = NW * MQ, C2CAP = NW * MP;
     constexpr int KD = (MQ * GD + 63) / 64, KT = (MA * GT + 63) / 64;
-    constexpr int GDF = GD < 6 ? GD : 6, GTF = GT < 6 ? GT : 6;   // slots gathered without a test (k + 1 = 5 entries per W_d row; 78 % of the W_d^T rows have <= 6)
+    constexpr int GDF = GD < 6 ? GD : 6, GTF = GT < 6 ? GT : (GT > 12 ? 4 : 6);   // slots gathered without a test (k + 1 = 5 entries per W_d row; 78 % of the W_d^T rows have <= 6)
     S* Pimg = reinterpret_cast<S*>(cldr_raw);          // [C2CAP][W]
     S* Qimg = Pimg + (size_t)C2CAP * W;                // [C1CAP][W]
     const int lane = threadIdx.x & 63;
@@ -875,7 +875,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_cldr(CldrGeom g, CldrMeta m, 
         Vec<S, VECT> pn[MP];            // x_{t+1} of this wave's rows of C2 (requested one step ahead; FOLD: r_{t+1})
         Vec<S, VECT> po[MPF], xo[MAF];  // FOLD: p_old of the same rows, x of the own rows
         Vec<S, VECT> pc[MA], qp[MA];    // x_t and q_t of its own rows
-        S fa[VECT], fb[VECT];           // FOLD: alpha, beta of this lane's columns
+        S fa[VECT], fb[VECT];           // FOLD: alpha, beta of this lane's columns (re-reading them with the rows of every step
+                                        // frees 8 registers in phase A but costs 2 % of the launch: 702 vs 687 us on cfg3)
 #pragma unroll
         for (int v = 0; v < VECT; ++v) fa[v] = fb[v] = S(0);
         if constexpr (Src::FOLD) {

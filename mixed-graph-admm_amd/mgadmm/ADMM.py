@@ -54,7 +54,8 @@ class ADMM_algorithm():
                       ADMM.py:221-222); default True so iterates match the reference
       tables          optional (connect_list, dist_list) to skip neighbour search (large graphs)
       reorder         internal node order: False/0, 'rcm'/1, 'cluster'/2 (greedy cluster growth; enables the
-                      LDS-tiled SpMM kernel) or 'auto' (cluster order for N >= 1024)
+                      LDS-tiled SpMM kernel and the fused Ldr^T Ldr kernel) or 'auto' (cluster order for every graph
+                      beyond the LDS-resident path, N > 512)
       record_cg_coeffs  keep alpha/beta of every CG iteration: True/False/'auto' (B <= 64)
       graph_backend   where the kNN search and the weight tables are computed: 'host' (NumPy, like the
                       reference's set-up code), 'gpu' (mgadmm.gpu_graph: HIP kernels) or 'auto' (gpu for
@@ -216,7 +217,9 @@ class ADMM_algorithm():
         N = self.n_nodes * Cn
         reorder = self.reorder
         if reorder == 'auto':
-            reorder = 2 if N >= 1024 else 0          # greedy cluster order (see csrc/graph.hip) for large graphs
+            # greedy cluster order (csrc/graph.hip) for every graph the LDS-resident path does not take: the tiled / fused
+            # streaming kernels need it (N = 600 ... 1000 at B = 4096: +18 % over the plain row kernels, tools/size_sweep.py)
+            reorder = 2 if N > 512 else 0
         reorder = {'rcm': 1, 'cluster': 2}[reorder] if isinstance(reorder, str) else int(reorder)
         dev = self.device
         if self.use_line_graph:

@@ -28,7 +28,7 @@ NMETRIC = 11
  M_RECOVER) = range(11)
 NPROF = 4
 (Q_LDS_OK, Q_LDS_TPG, Q_LDS_THREADS, Q_LDS_BYTES, Q_LDS_ROW_STRIDE, Q_NNZ_U, Q_NNZ_D, Q_NNZ_DT, Q_TILE_ROWS, Q_LDS_UNIFORM,
- Q_LDS_TAIL_PAIRS, Q_LDS_LEAD, Q_LDS_SLOTS, Q_LDS_CHUNK, Q_LDS_ROWS) = range(15)
+ Q_LDS_TAIL_PAIRS, Q_LDS_LEAD, Q_LDS_SLOTS, Q_LDS_CHUNK, Q_LDS_ROWS, Q_CLDR_SLOTS) = range(16)
 
 _i32p = C.POINTER(C.c_int32)
 _f32p = C.POINTER(C.c_float)

@@ -110,3 +110,52 @@ def test_random_problem_matches_oracle(seed):
                 lim = slack + (1 if nm == "CG_iter_x" and abl in ("DGTV", "UT") else 0)
                 assert np.abs(got - ref).max() <= lim, tag + " " + nm
         blk.close()
+
+
+def test_hub_node_rows_take_the_16_slot_fused_kernel():
+    """Nodes that 13 ... 15 others list among their nearest neighbours have W_d^T rows of up to 16 entries: more than the 12 entry slots of
+    the default instance of the fused Ldr^T Ldr kernel (k_cldr) -- the PEMS-like graphs of 600 ... 2000 nodes have such rows.
+    The engine then dispatches the 16-slot instance (MGADMM_Q_CLDR_SLOTS) instead of falling back to the two-pass operator;
+    operators, one CG solve and a 4-iteration solve against the oracle, float32 and float64."""
+    from mgadmm import utils as mu, _lib
+    n, hubs = 96, (0, 48)
+    edges, d = [], []
+    for h in hubs:                         # two stars of 13 leaves, the rest of each half a path hanging off the last leaf
+        for j in range(1, 14):
+            edges.append((h, h + j)); d.append(1.0 + 0.01 * j)
+        for j in range(14, 47):
+            edges.append((h + j - 1, h + j)); d.append(3.0 + 0.02 * j)
+    edges.append((47, 48)); d.append(4.0)
+    e = np.array(edges, dtype=np.int64)
+    ue = torch.from_numpy(np.concatenate([e, e[:, ::-1]]))
+    ud = torch.from_numpy(np.concatenate([d, d]))
+    cl, dl = mu.k_nearest_neighbors(n, ue, ud, 4)
+    cl = cl.long()
+    indeg = np.bincount(cl.numpy()[cl.numpy() >= 0].ravel(), minlength=n)
+    assert 12 < indeg.max() <= 16
+    T, t_in = 12, 6
+    r = (n / T) ** 0.5
+    meta = dict(n=n, T=T, t_in=t_in, rho=2 * r, rho_u=3 * r, rho_d=2 * r, mu_u=1.0, mu_d1=2.0, mu_d2=1.0, knn_cl=cl.numpy(),
+                knn_u_ew=mu.undirected_graph_from_distance(cl, dl, 20.0).numpy(),
+                knn_d_ew=mu.directed_graph_from_distance(cl, dl, 20.0).numpy())
+    rng = np.random.default_rng(5)
+    B = 256
+    x = rng.standard_normal((B, T, n, 1)).astype(np.float32)
+    y = (100 + 50 * rng.random((B, t_in, n, 1))).astype(np.float32)
+    o = make_oracle(meta, "knn")
+    k = 4
+    xo = o.combined_loop(y[:k].astype(np.float64), n_iters=4)
+    for dt, tol_op, tol_x in ((torch.float32, 2e-6, 1e-5), (torch.float64, 1e-12, 1e-9)):
+        blk = make_product(meta, "knn", compute_dtype=dt, path="stream", reorder="cluster")
+        xt = torch.from_numpy(x).to(dt)
+        assert rel(blk.apply_op_cLdr(xt), o.apply_op_cLdr(x.astype(np.float64))) < tol_op
+        assert rel(blk.LHS_x(xt), o.LHS_x(x.astype(np.float64))) < tol_op
+        h = blk._solvers[(1, dt)][0]
+        assert _lib.query(h, _lib.Q_CLDR_SLOTS) == 16
+        blk.max_ADMM_iter = 4
+        blk.check_stop = False
+        xs = blk.combined_loop(torch.from_numpy(y).to(dt), print_info=False)
+        assert rel(xs[:k], xo) < tol_x
+        got = np.array([v.tolist() for v in blk.CG_iter_x])[:, :k]
+        assert np.abs(got - np.array(o.hist.CG_iter_x)).max() <= (1 if dt == torch.float32 else 0)
+        blk.close()

@@ -2,7 +2,7 @@
 streaming path).  PEMS-like graphs (path + 11 % random chords, kNN k = 4 by shortest-path distance, built on the GPU), the
 cfg2 signal generator, a fixed number of ADMM iterations; B = 4096 or the largest power of two whose workspace fits 60 GB.
 
-    python tools/size_sweep.py [iters] > profiles/r03/size_sweep.txt
+    [MGADMM_SWEEP_SIZES=883,1000] python tools/size_sweep.py [iters] > profiles/r03/size_sweep.txt
 Prints N, path, time-group width, B, ms per ADMM iteration, sample-iterations/s and ELEMENT-iterations/s (B T N / time).
 """
 import math, os, sys, time
@@ -18,7 +18,8 @@ dev = torch.device("cuda", 0)
 print(f"# {iters} ADMM iterations per solve (second solve timed), fp32, kNN-directed, ablation None; element rate = B * 24 * N * iterations / s")
 print(f"{'N':>6s} {'path':>7s} {'TPG':>4s} {'B':>6s} {'ms/iter':>9s} {'sample-it/s':>12s} {'Gelem-it/s':>11s} {'CG x/zu/zd':>16s}")
 prev = None
-for n in (170, 256, 307, 341, 358, 420, 512, 600, 700, 1000, 2000, 5000):
+sizes = [int(v) for v in os.environ.get("MGADMM_SWEEP_SIZES", "170,256,307,341,358,420,512,600,700,883,1000,2000,5000").split(",")]
+for n in sizes:
     ue, ud = bench.pems_like_graph(n, int(round(n * 1.11)), seed=0)
     cl, dl = gpu_graph.k_nearest_neighbors(n, ue, ud, 4, device=dev)
     cl = cl.to(torch.int64)
@@ -28,6 +29,9 @@ for n in (170, 256, 307, 341, 358, 420, 512, 600, 700, 1000, 2000, 5000):
     while B * 24 * n * 4 * 22 > 60e9:
         B //= 2
     blk = bench.make_solver(n, cl, dl, info, dev)
+    if os.environ.get("MGADMM_SWEEP_REORDER"):          # experiments: 'cluster' / 'rcm' / '0' instead of the host's choice
+        v = os.environ["MGADMM_SWEEP_REORDER"]
+        blk.reorder = int(v) if v.isdigit() else v
     y = bench.synth_y(n, B, 12, 1, 0, dev)
     blk.max_ADMM_iter = iters
     blk.combined_loop(y, print_info=False)
