@@ -106,6 +106,41 @@ def test_cfg2_full_batch_lds_path_vs_oracle_windows():
     blk.close()
 
 
+# ---------------------------------------------------------------------------------------------- sizes around the path switch
+@pytest.mark.parametrize("n,path,tpg", [(341, "lds", 8), (358, "lds", 12), (512, "lds", 12), (600, "stream", 0), (883, "stream", 0)])
+def test_sizes_around_the_path_switch_vs_oracle_windows(n, path, tpg):
+    """PEMS-like graphs of 341 ... 883 nodes (PEMS03 = 358, PEMS07 = 883) at B = 512, the host's own choice of path and node
+    order: the last size of the 8-step LDS instance, the 12-step instances up to their limit of 512 nodes, and the streaming
+    path just beyond it (cluster order, fused Ldr^T Ldr kernel in its 12- or 16-slot instance) -- 4 windows x 4 iterations
+    against the oracle with the tolerances of the BASELINE configs."""
+    import math
+    import mgadmm
+    from mgadmm import _lib, gpu_graph
+    b = _bench()
+    dev = torch.device("cuda")
+    ue, ud = b.pems_like_graph(n, int(round(n * 1.11)), seed=0)
+    cl, dl = gpu_graph.k_nearest_neighbors(n, ue, ud, 4, device=dev)
+    cl = cl.to(torch.int64).cpu()
+    r = math.sqrt(n / 24)
+    info = dict(rho=2 * r, rho_u=3 * r, rho_d=2 * r, mu_u=1, mu_d1=2, mu_d2=1)
+    blk = mgadmm.ADMM_algorithm({"n_nodes": n}, info, use_kNN=True, k=4, u_sigma=50, d_sigma=50, tables=(cl, dl.cpu()),
+                                record_cg_coeffs=False)
+    B = 512
+    y = b.synth_y(n, B, 12, seed=1, offset=0, device=dev)
+    x = _solve(blk, y, 4)
+    h = blk._solvers[(1, torch.float32)][0]
+    assert _lib.lib.mgadmm_solver_path(h, B) == (_lib.PATH_LDS if path == "lds" else _lib.PATH_STREAM)
+    if path == "lds":
+        assert _lib.query(h, _lib.Q_LDS_TPG) == tpg
+    else:
+        assert _lib.query(h, _lib.Q_TILE_ROWS) == 8 and _lib.query(h, _lib.Q_CLDR_SLOTS) in (12, 16)
+    idx = np.array([0, 170, 341, B - 1])
+    o = _oracle(blk, cl, info)
+    xo = o.combined_loop(y[torch.as_tensor(idx, device=y.device)].double().cpu().numpy(), n_iters=4)
+    _check_windows(f"n{n}-{path}", blk, x, idx, o, xo)
+    blk.close()
+
+
 _CFG5_ORACLE = {}
 
 

@@ -25,7 +25,7 @@ for n in sizes:
     cl = cl.to(torch.int64)
     r = math.sqrt(n / 24)
     info = dict(rho=2 * r, rho_u=3 * r, rho_d=2 * r, mu_u=1, mu_d1=2, mu_d2=1)
-    B = 4096
+    B = int(os.environ.get("MGADMM_SWEEP_B", "4096"))
     while B * 24 * n * 4 * 22 > 60e9:
         B //= 2
     blk = bench.make_solver(n, cl, dl, info, dev)
