@@ -14,6 +14,9 @@ What sharding changes and what it does not
     iteration each shard can only test its own norms, so with ``check_stop=True`` a shard stops when ITS samples have
     converged (never later than the whole batch would).  Use a fixed iteration count when bit-identical results
     across different GPU counts matter; ``gather_history`` reports the iteration count of every shard.
+    ``sharded_solve_global_stop`` keeps the reference's semantics instead: one iteration at a time on every rank and an
+    all-reduce of six squared norms after each -- the stop test sees the whole-batch norms, the result is the one of the
+    unsharded run, at the price of one tiny collective and one solver call per iteration.
 """
 import torch
 import torch.distributed as dist
@@ -125,6 +128,59 @@ def sharded_solve(solve_fn, y, mask=None, *, gather="root", group=None, chunks=1
             if b > a:
                 out.append(pending[c][0][r][: b - a])
     return torch.cat(out, 0).to(y.device if dev.type == "cpu" else dev)
+
+
+def sharded_solve_global_stop(blk, y, mask=None, *, gather="root", group=None, dst=0):
+    """The reference's loop WITH its stop test on a sharded batch (ADMM.py:546-646: the test uses whole-batch norms).
+
+    ``blk`` is this rank's ``ADMM_algorithm``.  Every rank runs its block one ADMM iteration at a time (``solve`` resumed from
+    the state of the previous call: k calls of one iteration are bitwise one call of k iterations), the squared primal / dual
+    residual norms of the iteration are all-reduced (sum: a Frobenius norm over the batch is the root of the sum of the
+    shards' squares) and every rank applies ``max(primal) < ADMM_tol and max(dual) < ADMM_tol`` (ADMM.py:645) to the same
+    whole-batch values: all ranks stop after the same iteration, which is the iteration the unsharded run stops after.
+    A NaN / Inf on any rank (the reference's asserts, ADMM.py:534-606) is raised on every rank after the same iteration.
+    ``blk``'s history lists hold the per-shard values of the iterations that ran (``gather_history`` re-forms the whole-batch
+    ones).  Returns ``(x, n_iterations)``; ``x`` as ``sharded_solve`` returns it for the same ``gather``.
+    """
+    ws, rk = _world(group)
+    B = y.shape[0]
+    lo, hi = shard_bounds(B, ws, rk)
+    ys = y[lo:hi]
+    ms = mask[lo:hi] if mask is not None else None
+    ncomp = 1 + int(blk.ablation in ("None", "DGLR")) + int(blk.ablation != "DGLR")
+    n_max, save_stop = int(blk.max_ADMM_iter), blk.check_stop
+    tol = float(blk.ADMM_tol)
+    dev = _coll_device(group) if ws > 1 else torch.device("cpu")
+    x, state, n_it, failure = None, None, 0, None
+    blk.max_ADMM_iter, blk.check_stop = 1, False
+    try:
+        for it in range(n_max):
+            loc = torch.zeros(2 * ncomp + 1, dtype=torch.float64)
+            if hi > lo and failure is None:
+                try:
+                    x = blk.solve(ys, mask=ms, return_state=True, warm_start=state)[0]
+                    state = blk.state
+                    loc[:ncomp] = torch.tensor([float(v) ** 2 for v in blk.p_res_list[-1]], dtype=torch.float64)
+                    loc[ncomp:2 * ncomp] = torch.tensor([float(v) ** 2 for v in blk.d_res_list[-1]], dtype=torch.float64)
+                except AssertionError as e:          # NaN / Inf in this shard: tell the others, then raise everywhere
+                    failure = e
+                    loc[2 * ncomp] = 1.0
+            if ws > 1:
+                t = loc.to(dev)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                loc = t.cpu()
+            n_it = it + 1
+            if float(loc[2 * ncomp]) > 0:
+                raise failure if failure is not None else AssertionError(
+                    "NaN/Inf value in the ADMM iterates of another shard (reference asserts, ADMM.py:534-606)")
+            pri, dual = torch.sqrt(loc[:ncomp]), torch.sqrt(loc[ncomp:2 * ncomp])
+            if float(pri.max()) < tol and float(dual.max()) < tol:
+                break
+    finally:
+        blk.max_ADMM_iter, blk.check_stop = n_max, save_stop
+    if not gather or ws == 1:
+        return x, n_it
+    return sharded_solve(lambda _y, _m: x, y, mask, gather=gather, group=group, dst=dst), n_it
 
 
 # ---------------------------------------------------------------------------------------------- residual history

@@ -190,3 +190,30 @@ def test_resume_on_the_fused_streaming_path_with_the_folded_vector_update():
     assert torch.equal(x_res, x_full)
     np.testing.assert_array_equal(np.concatenate([first, np.array(blk.p_res_list)]), full)
     blk.close()
+
+
+@pytest.mark.parametrize("path", ["lds", "stream"])
+def test_global_stop_driver_equals_the_solvers_own_stop_test(path):
+    """mgadmm.dist.sharded_solve_global_stop (the reference's stop test on whole-batch norms for sharded runs: one iteration
+    per solver call, resumed) on ONE rank against the solver's own loop with check_stop=True: the same iteration count, the
+    same x bit for bit, the same residual history."""
+    import helpers
+    from mgadmm.dist import sharded_solve_global_stop
+    g = load_golden("g4_meta.npz")
+    y, _ = helpers.case_inputs(g, "pred", np.float32)
+    yt = torch.from_numpy(y)
+    blk = helpers.make_product(g, "knn", path=path)
+    blk.ADMM_tol = 60.0
+    blk.check_stop = True
+    blk.max_ADMM_iter = 40
+    x_ref = blk.solve(yt)[0]
+    p_ref, d_ref = np.array(blk.p_res_list), np.array(blk.d_res_list)
+    n_ref = len(p_ref)
+    assert 1 < n_ref < 40
+    blk._reset_history()
+    x, n_it = sharded_solve_global_stop(blk, yt)
+    assert n_it == n_ref and torch.equal(x, x_ref)
+    np.testing.assert_array_equal(np.array(blk.p_res_list), p_ref)
+    np.testing.assert_array_equal(np.array(blk.d_res_list), d_ref)
+    assert (blk.max_ADMM_iter, blk.check_stop) == (40, True)
+    blk.close()
