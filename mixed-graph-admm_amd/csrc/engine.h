@@ -32,7 +32,8 @@ enum VecId {
 constexpr int LAG = 2;          // CG iterations enqueued ahead of the host's convergence check
 constexpr int NRED_MAX = 6;
 constexpr int PROF_POOL = 32768;
-constexpr int LDS_MAXJ_POOL = 7;     // longest chunk of the LDS path's chunked schedule: 2 (J - 1) + 3 iterate buffers out of the workspace
+constexpr int LDS_MAXJ_POOL = LDS_MAXJ;   // longest chunk of the LDS path's chunked schedule: 2 (J - 1) + 3 iterate buffers -- 15 out of the
+                                          // workspace (enough for J = 7), the rest allocated on the first solve that asks for a longer chunk
 constexpr int NACT_LOG = 1 << 16;   // pinned log of the per-iteration active-sample counts (one int per CG iteration enqueued)
 
 template <typename S>
@@ -95,7 +96,8 @@ struct Engine : EngineBase {
     int lds_async = 1;            // MGADMM_LDS_ASYNC=0: one stream, the host tests the stop criterion after every iteration
     int* d_stop = nullptr;
     double* d_ps_ring = nullptr;  // [2][J][NMETRIC][Bp]: per-sample metric sums of the chunked schedule (two chunks in flight)
-    int lds_chunk = 7;            // MGADMM_LDS_CHUNK: ADMM iterations per k_admm_lds launch when the iteration count is fixed (1 .. LDS_MAXJ_POOL)
+    std::vector<float*> lds_ring_extra;   // iterate buffers beyond the 15 workspace vectors (chunks longer than 7 iterations)
+    int lds_chunk = LDS_MAXJ_POOL;   // MGADMM_LDS_CHUNK: ADMM iterations per k_admm_lds launch when the iteration count is fixed (1 .. LDS_MAXJ_POOL)
     hipStream_t st_side = nullptr;
     hipEvent_t ev_main[3] = {nullptr}, ev_side[3] = {nullptr};
     // profiling
@@ -120,6 +122,7 @@ struct Engine : EngineBase {
         fr(vec_pool); fr(partials); fr(d_rr); fr(d_alpha); fr(d_beta); fr(d_alpha_hist); fr(d_beta_hist);
         fr(d_active); fr(d_iters_tmp); fr(d_nact); fr(d_nonfinite); fr(d_ps); fr(d_hist); fr(d_dxps);
         fr(d_dxpart); fr(d_hist_ps); fr(d_cg_iters); fr(d_lds_csr); fr(d_m2); fr(d_stop); fr(d_ps_ring);
+        for (float* b : lds_ring_extra) if (b) (void)hipFree(b);
         if (st_side) (void)hipStreamDestroy(st_side);
         for (auto& e : ev_main) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_side) if (e) (void)hipEventDestroy(e);
@@ -1631,14 +1634,23 @@ struct Engine : EngineBase {
             // buffers for the iterates: the workspace vectors this path does not use otherwise
             static const int ring_ids[] = {V_XA, V_XB, V_ZUB, V_ZDB, V_PHIB, V_Y, V_MASK, V_R, V_P, V_Q, V_AP, V_RHS, V_TMP, V_IO0, V_IO1};
             constexpr int NRING = (int)(sizeof(ring_ids) / sizeof(ring_ids[0]));
-            static_assert(NRING >= 2 * (LDS_MAXJ_POOL - 1) + 3, "iterate buffers of the chunked schedule");
             const int J = sched == CHUNKS ? std::max(1, std::min(std::min(lds_chunk, LDS_MAXJ_POOL), max_it)) : 1;
+            {   // buffers beyond the workspace vectors for chunks longer than 7 iterations (kept for the solver's lifetime)
+                const int need = 2 * (J - 1) + 3 - NRING;
+                while ((int)lds_ring_extra.size() < need) {
+                    float* b = nullptr;
+                    MG_HIP(hipMalloc(&b, vec_elems * sizeof(S)));
+                    lds_ring_extra.push_back(b);
+                    ws_bytes += (int64_t)(vec_elems * sizeof(S));
+                }
+            }
+            auto ring = [&](int j) -> float* { return j < NRING ? (float*)vec[ring_ids[j]] : lds_ring_extra[j - NRING]; };
             // iterate k (k = 0: the initial guess) lives in xbuf(k)
             auto xbuf = [&](int k) -> float* {
                 if (k == max_it) return xo_;
-                if (sched != CHUNKS) return vec[ring_ids[k & 1]];
-                if (k % J == 0) return vec[ring_ids[(k / J) % 3]];                          // chunk boundary
-                return vec[ring_ids[3 + ((k / J) & 1) * (J - 1) + (k % J - 1)]];           // inside chunk k / J
+                if (sched != CHUNKS) return ring(k & 1);
+                if (k % J == 0) return ring((k / J) % 3);                          // chunk boundary
+                return ring(3 + ((k / J) & 1) * (J - 1) + (k % J - 1));           // inside chunk k / J
             };
             // zu, zd, phi and the dual variables: workspace vectors in the kernel's thread-major layout (lds_kernels.h,
             // lds_state_index); a warm start is converted in, the exported state is converted out at the end

@@ -89,7 +89,7 @@ def test_several_iterations_per_launch_equal_one_per_launch(abl, task, B):
     synchronous one-iteration-per-launch loop: iteration counts that are a multiple of J, leave a remainder, fit one chunk,
     and need more chunks than there are buffer sets."""
     meta = load_golden("g4_meta.npz")
-    for iters, chunk in ((1, 7), (5, 2), (6, 3), (7, 7), (8, 7), (16, 5), (23, 4)):
+    for iters, chunk in ((1, 7), (5, 2), (6, 3), (7, 7), (8, 7), (16, 5), (23, 4), (20, 10), (37, 16), (50, 12)):     # chunks > 7: iterate buffers beyond the workspace vectors
         a = _run("0", meta, abl, task, B, False, iters)
         b = _run("1", meta, abl, task, B, False, iters, chunk=chunk)
         assert a["n"] == b["n"] == iters
