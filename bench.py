@@ -265,7 +265,7 @@ def cpu_baseline(workload, n, cl, info, blk, y_dev, budget_s, steps):
     t0 = time.perf_counter()
     o.combined_loop(yc0, n_iters=2)
     per = (time.perf_counter() - t0) / (2.0 * ncal)                 # seconds per sample-iteration, one core, vectorised
-    it = max(1, min(steps, 20))
+    it = max(1, min(steps, 50))          # the same iteration count as the GPU line (later iterations are cheaper: fewer CG iterations)
     nb = int(max(1, min(y_dev.shape[0], 64, (budget_s / 3) / max(per * it, 1e-9))))      # vectorised batch on one core
     nl = int(max(workers, min(y_dev.shape[0], workers * (budget_s / 2) / max(per * it, 1e-9))))
     npz = os.path.join(tmp, "in.npz")
@@ -376,7 +376,7 @@ def roofline_from_prof(prof, workload, path="stream", blk=None, B=0, cg=None, st
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50, help="ADMM iterations of the timed solve (default 50: the iteration count of BASELINE config 1)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4"])
     ap.add_argument("--batch", type=int, default=0, help="override the per-GPU batch")
