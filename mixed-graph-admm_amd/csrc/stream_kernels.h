@@ -794,6 +794,11 @@ struct CldrSrcFold {
     const S* beta;
 };
 
+// Request schedule of k_cldr, compile-time switches of the measurements in DESIGN.md section 3b ("Round 3"); the defaults are
+// the measured best (make EXTRA=-DMG_CLDR_BATCH=2 builds a variant):
+//   MG_CLDR_BATCH  0: all rows of a step at once   1: own rows, wait, halo rows (default)   2: pair by pair, a wait after each
+//                  3: own rows, then the halo rows pair by pair
+//   MG_CLDR_EARLY  1: P image stored and the next rows requested at the START of phase C instead of its end
 #ifndef MG_CLDR_EARLY
 #define MG_CLDR_EARLY 0
 #endif
