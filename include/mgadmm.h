@@ -178,7 +178,7 @@ typedef enum {
     MGADMM_Q_LDS_SLOTS = 12,    /* 1: two LDS vectors park per-thread operands across the solves                    */
     MGADMM_Q_LDS_CHUNK = 13,    /* ADMM iterations per k_admm_lds launch when the iteration count is fixed          */
     MGADMM_Q_LDS_ROWS = 14,     /* LDS rows of an image: nodes + ghost rows                                         */
-    MGADMM_Q_CLDR_SLOTS = 15    /* W_d^T entry slots per row of the fused Ldr^T Ldr kernel in use (12 / 16); 0: two-pass */
+    MGADMM_Q_CLDR_SLOTS = 15    /* W_d^T entry slots per row of the fused Ldr^T Ldr kernel in use (12 / 16 / 24); 0: two-pass */
 } mgadmm_query_t;
 int mgadmm_solver_query(const mgadmm_solver* s, int32_t what, int64_t* out);
 

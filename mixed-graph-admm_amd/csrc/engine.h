@@ -283,7 +283,7 @@ struct Engine : EngineBase {
     typedef ClG<1, 8, 8, 11, 15, sizeof(S) == 4 ? 4 : 2> ClG2;   // 64 / 88 / 120 rows of 64 columns: 52 KiB (float) / 104 KiB (double); float: 128 VGPRs (6 waves per SIMD = 80 VGPRs spilled 87-100 of them in the folded form)
     typedef ClG<2, 8, 4, 8, 10, 4> ClG3;    // 32 / 64 / 80 rows of 128 columns: 72 KiB (float): twice the rows per tile, a smaller halo share
     typedef ClG<4, 16, 2, 3, 4, 4> ClG4;    // 32 / 48 / 64 rows of 256 columns, 16 waves: 112 KiB (float), one workgroup per CU
-    // W_d^T slots per row: 12, or 16 when a row is longer (round 3: the PEMS-like graphs of 600 ... 2000 nodes have rows of 13 and
+    // W_d^T slots per row: 12, or 16 / 24 when a row is longer (round 3: the PEMS-like graphs of 600 ... 2000 nodes have rows of 13 and
     // 14 entries and fell back to the two-pass path; the 16-slot instance is 5 % slower on graphs that do not need it).
     // W_d slots: 6 (no test at all) when no row is longer, else 8
     int cl_gt = 12;
@@ -315,7 +315,8 @@ struct Engine : EngineBase {
         cl_gt = 12;
         for (int i = 0; i < N; ++i) {
             if (A.rowptr[i + 1] - A.rowptr[i] > 6) cl_gd = 8;
-            if (At.rowptr[i + 1] - At.rowptr[i] > 12) cl_gt = 16;
+            const int tl = At.rowptr[i + 1] - At.rowptr[i];
+            if (tl > 12) cl_gt = std::max(cl_gt, tl > 16 ? 24 : 16);
         }
         CldrCaps caps{nw * ma, nw * mq, nw * mp, cl_gd, cl_gt};
         CldrTiles tl;
@@ -368,7 +369,8 @@ struct Engine : EngineBase {
     template <class G, template <typename, int> class E, template <typename, int> class SRC, class... A>
     int rows_cldr_g(const Geom& q, const SRC<S, G::VECT>& src, const int* live, A... a) {
         if (cl_gt == 12) return cl_gd == 6 ? rows_cldr_gd<G, 6, 12, E, SRC>(q, src, live, a...) : rows_cldr_gd<G, 8, 12, E, SRC>(q, src, live, a...);
-        return cl_gd == 6 ? rows_cldr_gd<G, 6, 16, E, SRC>(q, src, live, a...) : rows_cldr_gd<G, 8, 16, E, SRC>(q, src, live, a...);
+        if (cl_gt == 16) return cl_gd == 6 ? rows_cldr_gd<G, 6, 16, E, SRC>(q, src, live, a...) : rows_cldr_gd<G, 8, 16, E, SRC>(q, src, live, a...);
+        return cl_gd == 6 ? rows_cldr_gd<G, 6, 24, E, SRC>(q, src, live, a...) : rows_cldr_gd<G, 8, 24, E, SRC>(q, src, live, a...);
     }
     template <class G, int GD, int GT, template <typename, int> class E, template <typename, int> class SRC, class... A>
     int rows_cldr_gd(const Geom& q, const SRC<S, G::VECT>& src, const int* live, A... a) {

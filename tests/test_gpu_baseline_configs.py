@@ -111,7 +111,7 @@ def test_cfg2_full_batch_lds_path_vs_oracle_windows():
 def test_sizes_around_the_path_switch_vs_oracle_windows(n, path, tpg):
     """PEMS-like graphs of 341 ... 883 nodes (PEMS03 = 358, PEMS07 = 883) at B = 512, the host's own choice of path and node
     order: the last size of the 8-step LDS instance, the 12-step instances up to their limit of 512 nodes, and the streaming
-    path just beyond it (cluster order, fused Ldr^T Ldr kernel in its 12- or 16-slot instance) -- 4 windows x 4 iterations
+    path just beyond it (cluster order, fused Ldr^T Ldr kernel in its 12-, 16- or 24-slot instance) -- 4 windows x 4 iterations
     against the oracle with the tolerances of the BASELINE configs."""
     import math
     import mgadmm
@@ -133,7 +133,7 @@ def test_sizes_around_the_path_switch_vs_oracle_windows(n, path, tpg):
     if path == "lds":
         assert _lib.query(h, _lib.Q_LDS_TPG) == tpg
     else:
-        assert _lib.query(h, _lib.Q_TILE_ROWS) == 8 and _lib.query(h, _lib.Q_CLDR_SLOTS) in (12, 16)
+        assert _lib.query(h, _lib.Q_TILE_ROWS) == 8 and _lib.query(h, _lib.Q_CLDR_SLOTS) in (12, 16, 24)
     idx = np.array([0, 170, 341, B - 1])
     o = _oracle(blk, cl, info)
     xo = o.combined_loop(y[torch.as_tensor(idx, device=y.device)].double().cpu().numpy(), n_iters=4)

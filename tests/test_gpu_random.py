@@ -112,18 +112,20 @@ def test_random_problem_matches_oracle(seed):
         blk.close()
 
 
-def test_hub_node_rows_take_the_16_slot_fused_kernel():
+@pytest.mark.parametrize("leaves,slots", [(13, 16), (21, 24)])
+def test_hub_node_rows_take_the_wider_fused_kernel(leaves, slots):
     """Nodes that 13 ... 15 others list among their nearest neighbours have W_d^T rows of up to 16 entries: more than the 12 entry slots of
     the default instance of the fused Ldr^T Ldr kernel (k_cldr) -- the PEMS-like graphs of 600 ... 2000 nodes have such rows.
-    The engine then dispatches the 16-slot instance (MGADMM_Q_CLDR_SLOTS) instead of falling back to the two-pass operator;
+    The engine then dispatches the 16-slot (rows up to 16) or 24-slot (up to 24) instance (MGADMM_Q_CLDR_SLOTS) instead of falling
+    back to the two-pass operator;
     operators, one CG solve and a 4-iteration solve against the oracle, float32 and float64."""
     from mgadmm import utils as mu, _lib
     n, hubs = 96, (0, 48)
     edges, d = [], []
-    for h in hubs:                         # two stars of 13 leaves, the rest of each half a path hanging off the last leaf
-        for j in range(1, 14):
+    for h in hubs:                         # two stars of `leaves` leaves, the rest of each half a path hanging off the last leaf
+        for j in range(1, leaves + 1):
             edges.append((h, h + j)); d.append(1.0 + 0.01 * j)
-        for j in range(14, 47):
+        for j in range(leaves + 1, 47):
             edges.append((h + j - 1, h + j)); d.append(3.0 + 0.02 * j)
     edges.append((47, 48)); d.append(4.0)
     e = np.array(edges, dtype=np.int64)
@@ -132,7 +134,7 @@ def test_hub_node_rows_take_the_16_slot_fused_kernel():
     cl, dl = mu.k_nearest_neighbors(n, ue, ud, 4)
     cl = cl.long()
     indeg = np.bincount(cl.numpy()[cl.numpy() >= 0].ravel(), minlength=n)
-    assert 12 < indeg.max() <= 16
+    assert (12 if slots == 16 else 16) < indeg.max() <= slots
     T, t_in = 12, 6
     r = (n / T) ** 0.5
     meta = dict(n=n, T=T, t_in=t_in, rho=2 * r, rho_u=3 * r, rho_d=2 * r, mu_u=1.0, mu_d1=2.0, mu_d2=1.0, knn_cl=cl.numpy(),
@@ -151,7 +153,7 @@ def test_hub_node_rows_take_the_16_slot_fused_kernel():
         assert rel(blk.apply_op_cLdr(xt), o.apply_op_cLdr(x.astype(np.float64))) < tol_op
         assert rel(blk.LHS_x(xt), o.LHS_x(x.astype(np.float64))) < tol_op
         h = blk._solvers[(1, dt)][0]
-        assert _lib.query(h, _lib.Q_CLDR_SLOTS) == 16
+        assert _lib.query(h, _lib.Q_CLDR_SLOTS) == slots
         blk.max_ADMM_iter = 4
         blk.check_stop = False
         xs = blk.combined_loop(torch.from_numpy(y).to(dt), print_info=False)
