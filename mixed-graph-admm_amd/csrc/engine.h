@@ -32,6 +32,8 @@ enum VecId {
 constexpr int LAG = 2;          // CG iterations enqueued ahead of the host's convergence check
 constexpr int NRED_MAX = 6;
 constexpr int PROF_POOL = 32768;
+constexpr int LDS_SETS = 3;             // interior iterate-buffer sets / per-sample metric sets of the chunked schedule (chunks in flight)
+constexpr int LDS_NBOUND = 4;           // iterate buffers at the chunk boundaries
 constexpr int LDS_MAXJ_POOL = LDS_MAXJ;   // longest chunk of the LDS path's chunked schedule: 2 (J - 1) + 3 iterate buffers -- 15 out of the
                                           // workspace (enough for J = 7), the rest allocated on the first solve that asks for a longer chunk
 constexpr int NACT_LOG = 1 << 16;   // pinned log of the per-iteration active-sample counts (one int per CG iteration enqueued)
@@ -95,11 +97,11 @@ struct Engine : EngineBase {
     // stream for the whole-batch metric kernels and the events that order the two streams
     int lds_async = 1;            // MGADMM_LDS_ASYNC=0: one stream, the host tests the stop criterion after every iteration
     int* d_stop = nullptr;
-    double* d_ps_ring = nullptr;  // [2][J][NMETRIC][Bp]: per-sample metric sums of the chunked schedule (two chunks in flight)
+    double* d_ps_ring = nullptr;  // [LDS_SETS][J][NMETRIC][Bp]: per-sample metric sums of the chunked schedule
     std::vector<float*> lds_ring_extra;   // iterate buffers beyond the 15 workspace vectors (chunks longer than 7 iterations)
     int lds_chunk = LDS_MAXJ_POOL;   // MGADMM_LDS_CHUNK: ADMM iterations per k_admm_lds launch when the iteration count is fixed (1 .. LDS_MAXJ_POOL)
     hipStream_t st_side = nullptr;
-    hipEvent_t ev_main[3] = {nullptr}, ev_side[3] = {nullptr};
+    hipEvent_t ev_main[LDS_NBOUND] = {nullptr}, ev_side[LDS_NBOUND] = {nullptr};
     // profiling
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -1565,7 +1567,7 @@ struct Engine : EngineBase {
         MG_HIP(hipMalloc(&d_m2, sizeof(double) * T * N * (1 + (size_t)(Bmax + 63) / 64)));
         MG_HIP(hipMalloc(&d_stop, sizeof(int)));
         MG_HIP(hipMemset(d_stop, 0, sizeof(int)));
-        MG_HIP(hipMalloc(&d_ps_ring, sizeof(double) * 2 * LDS_MAXJ_POOL * MGADMM_NMETRIC * Bp_max));
+        MG_HIP(hipMalloc(&d_ps_ring, sizeof(double) * LDS_SETS * LDS_MAXJ_POOL * MGADMM_NMETRIC * Bp_max));
         {
             // helper stream of the overlapped outer loop: non-blocking (the caller's stream may be the legacy default stream,
             // which would serialise a blocking stream with itself), lowest priority (the k_admm_lds workgroups of the next
@@ -1638,7 +1640,7 @@ struct Engine : EngineBase {
             constexpr int NRING = (int)(sizeof(ring_ids) / sizeof(ring_ids[0]));
             const int J = sched == CHUNKS ? std::max(1, std::min(std::min(lds_chunk, LDS_MAXJ_POOL), max_it)) : 1;
             {   // buffers beyond the workspace vectors for chunks longer than 7 iterations (kept for the solver's lifetime)
-                const int need = 2 * (J - 1) + 3 - NRING;
+                const int need = LDS_SETS * (J - 1) + LDS_NBOUND - NRING;
                 while ((int)lds_ring_extra.size() < need) {
                     float* b = nullptr;
                     MG_HIP(hipMalloc(&b, vec_elems * sizeof(S)));
@@ -1651,8 +1653,8 @@ struct Engine : EngineBase {
             auto xbuf = [&](int k) -> float* {
                 if (k == max_it) return xo_;
                 if (sched != CHUNKS) return ring(k & 1);
-                if (k % J == 0) return ring((k / J) % 3);                          // chunk boundary
-                return ring(3 + ((k / J) & 1) * (J - 1) + (k % J - 1));           // inside chunk k / J
+                if (k % J == 0) return ring((k / J) % LDS_NBOUND);                                        // chunk boundary
+                return ring(LDS_NBOUND + ((k / J) % LDS_SETS) * (J - 1) + (k % J - 1));                    // inside chunk k / J
             };
             // zu, zd, phi and the dual variables: workspace vectors in the kernel's thread-major layout (lds_kernels.h,
             // lds_state_index); a warm start is converted in, the exported state is converted out at the end
@@ -1709,7 +1711,7 @@ struct Engine : EngineBase {
             a.nonfinite = d_nonfinite;
             a.stop = sched == DEVSTOP ? d_stop : nullptr;
             if (sched == DEVSTOP) MG_HIP(hipMemsetAsync(d_stop, 0, sizeof(int), st));
-            if (sched == CHUNKS) MG_HIP(hipMemsetAsync(d_ps_ring, 0, sizeof(double) * 2 * J * MGADMM_NMETRIC * Bp, st));
+            if (sched == CHUNKS) MG_HIP(hipMemsetAsync(d_ps_ring, 0, sizeof(double) * LDS_SETS * J * MGADMM_NMETRIC * Bp, st));
             const size_t K = p.max_cg_iter;
             int n_done = 0, rc_final = MGADMM_OK;
             // the whole-batch metrics of iteration `it` (delta_x_per_step, norms / means over the samples) on stream `s`
@@ -1729,18 +1731,21 @@ struct Engine : EngineBase {
                     a.J = Jc;
                     for (int k = 0; k <= Jc; ++k) a.xs[k] = xbuf(it0 + k);
                     a.cg_iters = d_cg_iters + (size_t)it0 * 3 * Bp;
-                    a.ps = d_ps_ring + (size_t)(c & 1) * J * MGADMM_NMETRIC * Bp;
-                    // launch c overwrites the iterate buffers and the metric sums that the metric kernels of chunk c-2 read
-                    if (c >= 2) MG_HIP(hipStreamWaitEvent(st, ev_side[(c - 2) % 3], 0));
+                    a.ps = d_ps_ring + (size_t)(c % LDS_SETS) * J * MGADMM_NMETRIC * Bp;
+                    // launch c overwrites the iterate buffers and the metric sums that the metric kernels of chunk c-3 read (interior
+                    // set and metric set c % 3; boundary buffer (c + 1) % 4 = the start of chunk c-3).  Two sets / three boundary
+                    // buffers (until the end of round 3) made launch c wait for the metrics of chunk c-2, which run BESIDE launch c-1
+                    // and get CU slots only when it drains: 0.45 ms between two 26 ms launches (profiles/r03/cfg2_iteration_timeline.txt)
+                    if (c >= LDS_SETS) MG_HIP(hipStreamWaitEvent(st, ev_side[(c - LDS_SETS) % LDS_NBOUND], 0));
                     MG_TRY(launch_lds(a, B));
-                    MG_HIP(hipEventRecord(ev_main[c % 3], st));
-                    MG_HIP(hipStreamWaitEvent(st_side, ev_main[c % 3], 0));
+                    MG_HIP(hipEventRecord(ev_main[c % LDS_NBOUND], st));
+                    MG_HIP(hipStreamWaitEvent(st_side, ev_main[c % LDS_NBOUND], 0));
                     for (int k = 0; k < Jc; ++k) MG_TRY(batch_metrics(it0 + k, a.ps + (size_t)k * MGADMM_NMETRIC * Bp, st_side));
-                    MG_HIP(hipEventRecord(ev_side[c % 3], st_side));
+                    MG_HIP(hipEventRecord(ev_side[c % LDS_NBOUND], st_side));
                     n_done = it0 + Jc;
                 }
                 if (c > 0)            // join the helper stream (its kernels run in order: the last event covers all)
-                    MG_HIP(hipStreamWaitEvent(st, ev_side[(c - 1) % 3], 0));
+                    MG_HIP(hipStreamWaitEvent(st, ev_side[(c - 1) % LDS_NBOUND], 0));
             }
             for (int it = 0; sched != CHUNKS && it < max_it; ++it) {
                 a.first = it == 0 && !state_in;      // phi = Ldr x0 is formed by the first launch of a cold start

@@ -14,8 +14,8 @@ CMD="python3 bench.py --steps 7 --warmup 1 --no-cpu-baseline --no-cfg4-leg --no-
 run() { name=$1; shift; echo "== $name"; rocprofv3 "$@" -d $W/$name -o p --output-format csv -- ${ALT:-$CMD} > $W/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $W/$name.log; exit 1; }; }
 run stats --kernel-trace --stats
 MGADMM_FOLD=0 run fold0 --kernel-trace --stats
-# cfg2 alone, 35 iterations = 5 launches of 7: the period between two k_admm_lds launches (side-stream metric kernels included)
-ALT="python3 bench.py --steps 35 --warmup 7 --no-cpu-baseline --no-cfg3-leg --no-prof" run timeline --kernel-trace
+# cfg2 alone, 64 iterations = 4 launches of 16: the period between two k_admm_lds launches (side-stream metric kernels included)
+ALT="python3 bench.py --steps 64 --warmup 16 --no-cpu-baseline --no-cfg3-leg --no-prof" run timeline --kernel-trace
 run fetch --pmc FETCH_SIZE
 run write --pmc WRITE_SIZE
 run sq1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
