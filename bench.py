@@ -457,9 +457,8 @@ def main():
 
     # warm-up (untimed): creates the solver workspace and the HIP event pool, pages kernels in
     run(max(1, args.warmup), False)
-    if not args.no_prof:
-        run(args.steps, True)               # the event pool of mgadmm_prof_begin is created on first use; a solve of the timed
-                                            # length also allocates whatever depends on the iteration count
+    run(args.steps, not args.no_prof)       # a solve of the timed length allocates whatever depends on the iteration count (iterate
+    if not args.no_prof:                    # buffers of the chunked schedule); the event pool of mgadmm_prof_begin is created on first use
         blk.prof_end()
     sampler = DeviceSampler(DeviceSampler.pci_address(local), period=None) if rank == 0 and args.device_state else None
     barrier()
